@@ -1,0 +1,51 @@
+// Internal declarations shared by the translation units of libmistereo.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+#include "mi_stereo.h"
+
+struct mis_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;   // created by mis_create
+    hipStream_t stream = nullptr;       // stream work is enqueued on (own_stream by default)
+    std::string err;
+
+    // bound image pair
+    const void* img[2] = { nullptr, nullptr };   // device pointers
+    void* owned_img[2] = { nullptr, nullptr };   // set when mis_upload_pair allocated them
+    size_t owned_img_bytes = 0;
+    int dtype = -1, width = 0, height = 0;
+    size_t stride = 0;                            // bytes
+    uint64_t pair_serial = 0;                     // bumped on every bind/upload
+
+    // dense-NCC workspace (see ncc_kernels.hip)
+    struct NccWs* ncc = nullptr;
+    // FFT-correlation workspace (see xcorr_kernels.hip)
+    struct XcorrWs* xc = nullptr;
+    // triangulation scratch
+    void* tri_buf = nullptr; size_t tri_bytes = 0;
+};
+
+int mis_fail(mis_ctx* ctx, int code, const char* fmt, ...);
+#define MIS_HIP(ctx, call)                                                             \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return mis_fail((ctx), MIS_ERR_DEVICE, "%s failed: %s (%s:%d)", #call,     \
+                            hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+
+// grows *buf to at least `bytes` (device memory); contents are not preserved
+int mis_reserve(mis_ctx* ctx, void** buf, size_t* cap, size_t bytes);
+
+void mis_ncc_release(mis_ctx* ctx);
+void mis_xcorr_release(mis_ctx* ctx);
+
+static inline int mis_pixel_bytes(int dtype)
+{
+    return dtype == MIS_U8 ? 1 : dtype == MIS_U16 ? 2 : dtype == MIS_F32 ? 4 : 0;
+}

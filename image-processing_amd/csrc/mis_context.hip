@@ -1,0 +1,152 @@
+// Context, error reporting and image-pair management of libmistereo.so.
+//
+// The context replaces the reference's process globals (image3.cpp:340-344) and its per-call
+// allocate / plan / free cycle (image3.cpp:357-372, 421-425): device buffers are owned here and
+// reused across calls.
+
+#include "mis_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <mutex>
+
+static std::string g_create_err;
+static std::mutex g_create_mu;
+
+int mis_fail(mis_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else { std::lock_guard<std::mutex> g(g_create_mu); g_create_err = buf; }
+    return code;
+}
+
+int mis_reserve(mis_ctx* ctx, void** buf, size_t* cap, size_t bytes)
+{
+    if (*cap >= bytes && *buf) return MIS_OK;
+    if (*buf) { MIS_HIP(ctx, hipFree(*buf)); *buf = nullptr; *cap = 0; }
+    MIS_HIP(ctx, hipMalloc(buf, bytes));
+    *cap = bytes;
+    return MIS_OK;
+}
+
+extern "C" {
+
+const char* mis_version(void) { return "libmistereo gfx950 " __DATE__; }
+
+int mis_create(int device_id, mis_ctx** out)
+{
+    if (!out) return mis_fail(nullptr, MIS_ERR_ARG, "mis_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return mis_fail(nullptr, MIS_ERR_DEVICE, "mis_create: no HIP device (%s); there is no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "count 0");
+    if (device_id < 0 || device_id >= n)
+        return mis_fail(nullptr, MIS_ERR_ARG, "mis_create: device %d out of range (have %d)", device_id, n);
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return mis_fail(nullptr, MIS_ERR_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return mis_fail(nullptr, MIS_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return mis_fail(nullptr, MIS_ERR_UNSUPPORTED, "mis_create: device %d is %s; this library is built for gfx950 only",
+                        device_id, prop.gcnArchName);
+    mis_ctx* c = new mis_ctx();
+    c->device = device_id;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return mis_fail(nullptr, MIS_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->stream = c->own_stream;
+    *out = c;
+    return MIS_OK;
+}
+
+int mis_destroy(mis_ctx* ctx)
+{
+    if (!ctx) return MIS_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    mis_ncc_release(ctx);
+    mis_xcorr_release(ctx);
+    if (ctx->tri_buf) hipFree(ctx->tri_buf);
+    for (int i = 0; i < 2; i++) if (ctx->owned_img[i]) hipFree(ctx->owned_img[i]);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MIS_OK;
+}
+
+const char* mis_last_error(const mis_ctx* ctx)
+{
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> g(g_create_mu);
+    return g_create_err.c_str();
+}
+
+int mis_set_stream(mis_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MIS_OK;
+}
+
+int mis_synchronize(mis_ctx* ctx)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MIS_OK;
+}
+
+static int check_pair_args(mis_ctx* ctx, const void* a, const void* b, int dtype, int w, int h, size_t stride)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    int bpp = mis_pixel_bytes(dtype);
+    if (!a || !b) return mis_fail(ctx, MIS_ERR_ARG, "image pointer is NULL");
+    if (!bpp) return mis_fail(ctx, MIS_ERR_ARG, "unknown pixel type %d", dtype);
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536) return mis_fail(ctx, MIS_ERR_ARG, "bad raster size %d x %d", w, h);
+    if (stride < (size_t)w * bpp) return mis_fail(ctx, MIS_ERR_ARG, "row stride %zu smaller than a row (%zu)", stride, (size_t)w * bpp);
+    if (stride % bpp) return mis_fail(ctx, MIS_ERR_ARG, "row stride %zu not a multiple of the pixel size", stride);
+    return MIS_OK;
+}
+
+int mis_bind_pair_device(mis_ctx* ctx, const void* d_img1, const void* d_img2, int dtype,
+                         int width, int height, size_t row_stride_bytes)
+{
+    int rc = check_pair_args(ctx, d_img1, d_img2, dtype, width, height, row_stride_bytes);
+    if (rc) return rc;
+    ctx->img[0] = d_img1; ctx->img[1] = d_img2;
+    ctx->dtype = dtype; ctx->width = width; ctx->height = height; ctx->stride = row_stride_bytes;
+    ctx->pair_serial++;
+    return MIS_OK;
+}
+
+int mis_upload_pair(mis_ctx* ctx, const void* img1, const void* img2, int dtype,
+                    int width, int height, size_t row_stride_bytes)
+{
+    int rc = check_pair_args(ctx, img1, img2, dtype, width, height, row_stride_bytes);
+    if (rc) return rc;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    size_t rowb = (size_t)width * mis_pixel_bytes(dtype);
+    size_t bytes = rowb * height;
+    if (ctx->owned_img_bytes < bytes) {
+        for (int i = 0; i < 2; i++) {
+            if (ctx->owned_img[i]) { MIS_HIP(ctx, hipFree(ctx->owned_img[i])); ctx->owned_img[i] = nullptr; }
+        }
+        ctx->owned_img_bytes = 0;
+        for (int i = 0; i < 2; i++) MIS_HIP(ctx, hipMalloc(&ctx->owned_img[i], bytes));
+        ctx->owned_img_bytes = bytes;
+    }
+    const void* src[2] = { img1, img2 };
+    for (int i = 0; i < 2; i++)
+        MIS_HIP(ctx, hipMemcpy2DAsync(ctx->owned_img[i], rowb, src[i], row_stride_bytes, rowb, height,
+                                      hipMemcpyHostToDevice, ctx->stream));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return mis_bind_pair_device(ctx, ctx->owned_img[0], ctx->owned_img[1], dtype, width, height, rowb);
+}
+
+}  // extern "C"

@@ -1,0 +1,589 @@
+// Dense windowed zero-mean NCC over a horizontal disparity range, gfx950.
+//
+// What is computed (per left pixel, per disparity d):
+//   score(d) = cov(L window, R window shifted by d) / sqrt(var L * var R)
+// with the first maximum over d, its two neighbours (parabolic subpixel) and optionally the best
+// score further than 1 px away.  This is the dense mode the reference leaves disabled
+// (image3.cpp:775-811) and names as a TODO (image3.cpp:866-870); sign and tie-break follow
+// image3.cpp:696-699 and image3.cpp:486-501.
+//
+// Mapping onto the machine
+//   lane        <-> disparity (64 consecutive d per wavefront, one "chunk")
+//   wavefront   <-> one chunk of disparities for a strip of WT pixel columns, walking down rows
+//   workgroup   <-> all chunks of the disparity range for that strip (<= 16 wavefronts)
+// so every window sum is a running sum held in one lane's registers: the column sums of the
+// product image slide down the rows (one v_dot2c_f32_f16 per column, row and disparity: it adds
+// the entering row's product and subtracts the leaving row's), the window sum slides along the
+// strip.  The left-image operand of every multiply is the same for all lanes (scalar loads); the
+// right-image operand sits in LDS, where lane d reads element x-d.
+//
+// Exactness: pixels are shifted by 128 into [-128,127] (NCC does not change); every product,
+// column sum and window sum is an integer below 2^24 and therefore exact in f32.
+#include "mis_common.h"
+
+#include <math.h>
+#include <stdio.h>
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+struct NccWs {
+    // per-pixel tables, pitch P elements per row, H rows
+    uint32_t* Lpack = nullptr;  // half2( L'(x,y), -L'(x,y-W) )      (0 outside the raster)
+    float* negc = nullptr;      // -round(S_L/N)
+    float* negg = nullptr;      // -(S_L - N*round(S_L/N))/N
+    float* iL = nullptr;        // 1/sqrt(sum (L-mean)^2), 0 when the window is flat or does not fit
+    uint32_t* Rpack = nullptr;  // half2( R'(x,y), R'(x,y-W) )
+    float* Rsr = nullptr;       // S_R (window sum of R')
+    float* Rir = nullptr;       // 1/sqrt(sum (R-mean)^2), 0 when flat, NaN where the window does not fit
+    int32_t* hs1 = nullptr;     // horizontal window sums (scratch)
+    int32_t* hs2 = nullptr;
+    size_t cap_px = 0;          // capacity in pixels (pitch*rows) of the arrays above
+    int pitch = 0, rows = 0;
+    uint64_t pair_serial = 0;   // tables valid for this pair ...
+    int window = 0;             // ... and this window
+};
+
+void mis_ncc_release(mis_ctx* ctx)
+{
+    NccWs* w = ctx->ncc;
+    if (!w) return;
+    void* bufs[] = { w->Lpack, w->negc, w->negg, w->iL, w->Rpack, w->Rsr, w->Rir, w->hs1, w->hs2 };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    delete w;
+    ctx->ncc = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pre-pass 1: horizontal window sums of p' = p - 128 and p'^2, one thread per pixel.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ncc_hsum_kernel(const T* __restrict__ img, size_t stride_px,
+                                                       int W, int H, int r, int pitch,
+                                                       int32_t* __restrict__ hs1, int32_t* __restrict__ hs2)
+{
+    __shared__ int tile[256 + 2 * 16];
+    const int y = blockIdx.y;
+    const int x0 = blockIdx.x * 256;
+    const T* row = img + (size_t)y * stride_px;
+    for (int i = threadIdx.x; i < 256 + 2 * r; i += 256) {
+        int x = x0 - r + i;
+        tile[i] = (x >= 0 && x < W) ? (int)row[x] - 128 : 0;
+    }
+    __syncthreads();
+    int x = x0 + threadIdx.x;
+    if (x >= pitch) return;
+    int s1 = 0, s2 = 0;
+    for (int i = 0; i <= 2 * r; i++) { int v = tile[threadIdx.x + i]; s1 += v; s2 += v * v; }
+    hs1[(size_t)y * pitch + x] = s1;
+    hs2[(size_t)y * pitch + x] = s2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pre-pass 2: vertical sums -> window statistics, and the packed row pairs.
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool LEFT>
+__global__ __launch_bounds__(256) void ncc_stats_kernel(const T* __restrict__ img, size_t stride_px,
+                                                        int W, int H, int r, int pitch,
+                                                        const int32_t* __restrict__ hs1,
+                                                        const int32_t* __restrict__ hs2,
+                                                        uint32_t* __restrict__ pack,
+                                                        float* __restrict__ o0,   // LEFT: negc   RIGHT: S_R
+                                                        float* __restrict__ o1,   // LEFT: negg   RIGHT: iR
+                                                        float* __restrict__ o2)   // LEFT: iL
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= pitch) return;
+    const size_t o = (size_t)y * pitch + x;
+    const int Wn = 2 * r + 1;
+    // packed pair: this row and the row Wn above
+    float a = 0.f, b = 0.f;
+    if (x < W) {
+        a = (float)((int)img[(size_t)y * stride_px + x] - 128);
+        if (y - Wn >= 0) b = (float)((int)img[(size_t)(y - Wn) * stride_px + x] - 128);
+    }
+    half2_t h;
+    h.x = (_Float16)a;
+    h.y = (_Float16)(LEFT ? -b : b);
+    pack[o] = __builtin_bit_cast(uint32_t, h);
+
+    const bool colok = (x >= r && x < W - r);
+    const bool rowok = (y >= r && y < H - r);
+    float v0 = 0.f, v1 = LEFT ? 0.f : (colok ? 0.f : __builtin_nanf("")), v2 = 0.f;
+    if (colok && rowok) {
+        long long s1 = 0, s2 = 0;
+        for (int j = -r; j <= r; j++) {
+            s1 += hs1[(size_t)(y + j) * pitch + x];   // hs*[..][x]: horizontal window centred at x
+            s2 += hs2[(size_t)(y + j) * pitch + x];
+        }
+        const long long N = (long long)Wn * Wn;
+        const long long var = N * s2 - s1 * s1;            // N * sum (p-mean)^2, exact
+        const float inv = var > 0 ? (float)sqrt((double)N / (double)var) : 0.f;
+        if (LEFT) {
+            long long c = (2 * s1 + N) / (2 * N);          // round(s1/N) for s1 >= 0 ...
+            if (2 * s1 + N < 0) c = -((-(2 * s1 + N) + 2 * N - 1) / (2 * N));   // ... floor for negatives
+            const long long rem = s1 - N * c;
+            v0 = -(float)c;
+            v1 = -(float)((double)rem / (double)N);
+            v2 = inv;
+        } else {
+            v0 = (float)s1;
+            v1 = inv;
+        }
+    }
+    o0[o] = v0;
+    o1[o] = v1;
+    if (LEFT) o2[o] = v2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Main kernel
+// ---------------------------------------------------------------------------------------------
+struct NccArgs {
+    int W, H, pitch;
+    int dmin, dmax, nchunk;
+    int row0, row1;      // output rows [row0,row1), already clipped to [r, H-r)
+    int band_rows;       // rows per workgroup
+    int out_pitch;       // elements per output row (== W)
+};
+
+#define DPP_QUAD_1032 0xB1
+#define DPP_QUAD_2301 0x4E
+#define DPP_ROW_ROR4 0x124
+#define DPP_ROW_ROR8 0x128
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, ROWMASK, 0xF, false));
+}
+
+// maximum over the 64 lanes, NaN operands ignored; every lane may hold a different partial value
+// afterwards, lane 63 holds the full maximum
+__device__ __forceinline__ float wave_max_to_lane63(float v)
+{
+    v = fmaxf(v, dpp_f<DPP_QUAD_1032>(v));
+    v = fmaxf(v, dpp_f<DPP_QUAD_2301>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_ROR4>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_ROR8>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_BCAST15, 0xA>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_BCAST31, 0xC>(v));
+    return v;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// old with lane `lane` (a compile-time constant after unrolling) replaced by the wave-uniform val
+__device__ __forceinline__ float writelane_f(float val, int lane, float old)
+{
+    int sval = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, val));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(lane));
+    return old;
+}
+
+// result fields exchanged between the chunk wavefronts of a workgroup, per column
+enum { F_BEST = 0, F_IDX, F_SM, F_SP, F_E0, F_E63, F_SEC, NFIELD };
+
+template <int R, int WT, bool WANT2>
+__global__ __launch_bounds__(1024) void ncc_main_kernel(
+    NccArgs a,
+    const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
+    const float* __restrict__ gIL, const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr,
+    const float* __restrict__ gRir, float* __restrict__ oDisp, float* __restrict__ oPeak,
+    int16_t* __restrict__ oIdisp, float* __restrict__ oPeak2)
+{
+    constexpr int WN = 2 * R + 1;
+    constexpr int NC = WT + 2 * R;          // column sums held per lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int lane = threadIdx.x & 63;
+    const int chunk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nchunk = a.nchunk;
+    const int nthreads = nchunk * 64;
+    const int LEN = NC + nchunk * 64;        // staged right-image columns per row
+
+    float* sBp = (float*)smem_raw;                 // [2][LEN] packed half2 pairs (as raw dwords)
+    float* sSR = sBp + 2 * LEN;                    // [2][LEN]
+    float* sIR = sSR + 2 * LEN;                    // [2][LEN]
+    float* sRes = sIR + 2 * LEN;                   // [2][nchunk][NFIELD][WT]
+
+    const int x0 = R + blockIdx.x * WT;            // first output column of the strip
+    const int yb0 = a.row0 + blockIdx.y * a.band_rows;
+    const int yb1 = min(yb0 + a.band_rows, a.row1);
+    if (yb0 >= yb1) return;
+    const int nrows = yb1 - yb0;
+    const int T = 2 * R + nrows;                   // row steps: 2R warm-up + one per output row
+
+    const int dtop = a.dmin + nchunk * 64 - 1;     // largest disparity any lane stands for
+    const int d = a.dmin + chunk * 64 + lane;      // this lane's disparity
+    const int loff = dtop - d;                     // LDS index of (column k, this lane) is k + loff
+    const int xr0 = x0 - R - dtop;                 // raster column of LDS index 0
+    const float bias = (d <= a.dmax) ? 0.f : -INFINITY;
+
+    float C[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) C[k] = 0.f;
+
+    const int P = a.pitch;
+
+    // ---- stage step 0 ----
+    {
+        const int ynew = yb0 - R;
+        for (int i = threadIdx.x; i < LEN; i += nthreads) {
+            int xr = xr0 + i;
+            bool in = (xr >= 0 && xr < a.W);
+            uint32_t bp = in ? gRpack[(size_t)ynew * P + xr] : 0u;
+            sBp[i] = __builtin_bit_cast(float, bp);
+        }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < T; t++) {
+        const int buf = t & 1;
+        const int ynew = yb0 - R + t;              // row entering the window
+        const bool warm = (t < WN);                // leaving row is above the first window: ignore it
+        const bool score = (t >= 2 * R);
+        const int yout = ynew - R;
+
+        // ---- prefetch next step's right-image row into registers ----
+        uint32_t nbp[2] = { 0u, 0u };
+        float nsr[2] = { 0.f, 0.f }, nir[2] = { 0.f, 0.f };
+        const bool have_next = (t + 1 < T);
+        const bool next_score = (t + 1 >= 2 * R);
+        if (have_next) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                int i = threadIdx.x + q * nthreads;
+                if (i < LEN) {
+                    int xr = xr0 + i;
+                    bool in = (xr >= 0 && xr < a.W);
+                    nbp[q] = in ? gRpack[(size_t)(ynew + 1) * P + xr] : 0u;
+                    if (next_score) {
+                        nsr[q] = in ? gRsr[(size_t)(yout + 1) * P + xr] : 0.f;
+                        nir[q] = in ? gRir[(size_t)(yout + 1) * P + xr] : __builtin_nanf("");
+                    }
+                }
+            }
+        }
+
+        // ---- column sums: add the entering row, drop the leaving row ----
+        const float* bp = sBp + buf * LEN + loff;
+        const uint32_t* lrow = gLpack + (size_t)ynew * P + (x0 - R);
+        const uint32_t amask = warm ? 0x0000FFFFu : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            uint32_t av = lrow[k] & amask;
+            half2_t ah = __builtin_bit_cast(half2_t, av);
+            half2_t bh = __builtin_bit_cast(half2_t, bp[k]);
+            C[k] = __builtin_amdgcn_fdot2(ah, bh, C[k], false);
+        }
+
+        if (score) {
+            const float* sr = sSR + buf * LEN + loff + R;
+            const float* ir = sIR + buf * LEN + loff + R;
+            const float* ncrow = gNegc + (size_t)yout * P + x0;
+            const float* ngrow = gNegg + (size_t)yout * P + x0;
+            float rBest = -INFINITY, rIdx = 0.f, rSm = 0.f, rSp = 0.f, rE0 = 0.f, rE63 = 0.f, rSec = -INFINITY;
+            float S = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2 * R; k++) S += C[k];
+#pragma unroll
+            for (int j = 0; j < WT; j++) {
+                S += C[j + 2 * R];
+                const float nc = ncrow[j];
+                const float ng = ngrow[j];
+                const float srv = sr[j];
+                float tt = __builtin_fmaf(nc, srv, S);       // S - c*S_R, exact
+                float cov = __builtin_fmaf(ng, srv, tt);     // - (rem/N)*S_R
+                float sc = __builtin_fmaf(cov, ir[j], bias);
+                S -= C[j];
+
+                // ---- argmax over the 64 disparities of this wavefront ----
+                float red = wave_max_to_lane63(sc);
+                float mx = readlane_f(red, 63);
+                unsigned long long hit = __ballot(sc == mx);
+                int idx = hit ? (int)__builtin_ctzll(hit) : 0;
+                float sm = readlane_f(sc, (idx + 63) & 63);
+                float sp = readlane_f(sc, (idx + 1) & 63);
+                float e0 = readlane_f(sc, 0);
+                float e63 = readlane_f(sc, 63);
+                rBest = writelane_f(mx, j, rBest);
+                rIdx = writelane_f(__builtin_bit_cast(float, idx), j, rIdx);
+                rSm = writelane_f(sm, j, rSm);
+                rSp = writelane_f(sp, j, rSp);
+                rE0 = writelane_f(e0, j, rE0);
+                rE63 = writelane_f(e63, j, rE63);
+                if (WANT2) {
+                    int dl = lane - idx;
+                    float sc2 = (dl >= -1 && dl <= 1) ? -INFINITY : sc;
+                    float red2 = wave_max_to_lane63(sc2);
+                    rSec = writelane_f(readlane_f(red2, 63), j, rSec);
+                }
+            }
+            if (lane < WT) {
+                float* res = sRes + ((size_t)(buf * nchunk + chunk) * NFIELD) * WT + lane;
+                res[F_BEST * WT] = rBest;
+                res[F_IDX * WT] = rIdx;
+                res[F_SM * WT] = rSm;
+                res[F_SP * WT] = rSp;
+                res[F_E0 * WT] = rE0;
+                res[F_E63 * WT] = rE63;
+                if (WANT2) res[F_SEC * WT] = rSec;
+            }
+        }
+
+        // ---- publish the prefetched row ----
+        if (have_next) {
+            const int nb = buf ^ 1;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                int i = threadIdx.x + q * nthreads;
+                if (i < LEN) {
+                    sBp[nb * LEN + i] = __builtin_bit_cast(float, nbp[q]);
+                    if (next_score) { sSR[nb * LEN + i] = nsr[q]; sIR[nb * LEN + i] = nir[q]; }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- one wavefront merges the chunks of this row and writes the outputs ----
+        if (score && chunk == (t % nchunk) && lane < WT) {
+            const int x = x0 + lane;
+            if (x < a.W - R) {
+                const float* res = sRes + (size_t)(buf * nchunk) * NFIELD * WT + lane;
+                float best = -INFINITY, sm = NAN, sp = NAN;
+                int bc = -1, bidx = 0;
+                for (int c = 0; c < nchunk; c++) {
+                    const float* rc = res + (size_t)c * NFIELD * WT;
+                    float v = rc[F_BEST * WT];
+                    if (v > best) { best = v; bc = c; bidx = __builtin_bit_cast(int, rc[F_IDX * WT]); }
+                }
+                const size_t o = (size_t)yout * a.out_pitch + x;
+                if (bc < 0) {
+                    oDisp[o] = (float)MIS_INVALID_DISP;
+                    oPeak[o] = 0.f;
+                    if (oIdisp) oIdisp[o] = (int16_t)MIS_INVALID_DISP;
+                    if (WANT2) oPeak2[o] = -1.f;
+                } else {
+                    const float* rc = res + (size_t)bc * NFIELD * WT;
+                    if (bidx > 0) sm = rc[F_SM * WT];
+                    else if (bc > 0) sm = rc[F_E63 * WT - (ptrdiff_t)NFIELD * WT];
+                    if (bidx < 63) sp = rc[F_SP * WT];
+                    else if (bc + 1 < nchunk) sp = rc[F_E0 * WT + (ptrdiff_t)NFIELD * WT];
+                    float delta = 0.f;
+                    // neighbours that are not valid disparities hold NaN or -inf
+                    if (sm > -INFINITY && sp > -INFINITY) {
+                        float den = 2.f * (sm - 2.f * best + sp);
+                        if (den != 0.f) {
+                            delta = (sm - sp) / den;
+                            delta = fminf(0.5f, fmaxf(-0.5f, delta));
+                        }
+                    }
+                    const int dbest = a.dmin + bc * 64 + bidx;
+                    const float il = gIL[(size_t)yout * P + x];
+                    oDisp[o] = (float)dbest + delta;
+                    oPeak[o] = best * il;
+                    if (oIdisp) oIdisp[o] = (int16_t)dbest;
+                    if (WANT2) {
+                        float sec = -INFINITY;
+                        for (int c = 0; c < nchunk; c++) {
+                            const float* r2 = res + (size_t)c * NFIELD * WT;
+                            float v;
+                            if (c == bc) v = r2[F_SEC * WT];
+                            else if (c == bc + 1 && bidx == 63) {
+                                // lane 0 of the next chunk is excluded
+                                int i2 = __builtin_bit_cast(int, r2[F_IDX * WT]);
+                                v = (i2 != 0) ? r2[F_BEST * WT] : fmaxf(r2[F_SP * WT], r2[F_SEC * WT]);
+                            } else if (c == bc - 1 && bidx == 0) {
+                                int i2 = __builtin_bit_cast(int, r2[F_IDX * WT]);
+                                v = (i2 != 63) ? r2[F_BEST * WT] : fmaxf(r2[F_SM * WT], r2[F_SEC * WT]);
+                            } else v = r2[F_BEST * WT];
+                            if (v > sec) sec = v;     // NaN and -inf never win
+                        }
+                        oPeak2[o] = (sec > -INFINITY) ? sec * il : -1.f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// fills the frame border (pixels whose window does not fit) of rows [row0,row1)
+__global__ __launch_bounds__(256) void ncc_border_kernel(float* disp, float* peak, int16_t* idisp, float* peak2,
+                                                         int W, int H, int r, int row0, int row1)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = row0 + blockIdx.y;
+    if (x >= W || y >= row1) return;
+    const bool inside = (x >= r && x < W - r && y >= r && y < H - r);
+    if (inside) return;
+    const size_t o = (size_t)y * W + x;
+    disp[o] = (float)MIS_INVALID_DISP;
+    peak[o] = 0.f;
+    if (idisp) idisp[o] = (int16_t)MIS_INVALID_DISP;
+    if (peak2) peak2[o] = -1.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+static int ncc_prepare(mis_ctx* ctx, int window)
+{
+    NccWs* w = ctx->ncc;
+    if (!w) { w = new NccWs(); ctx->ncc = w; }
+    const int W = ctx->width, H = ctx->height, r = window / 2;
+    const int pitch = ((W + 64 + 63) / 64) * 64 + 64;   // room for one strip past the right edge
+    const size_t npx = (size_t)pitch * H;
+    if (w->cap_px < npx) {
+        void** bufs[] = { (void**)&w->Lpack, (void**)&w->negc, (void**)&w->negg, (void**)&w->iL,
+                          (void**)&w->Rpack, (void**)&w->Rsr, (void**)&w->Rir, (void**)&w->hs1, (void**)&w->hs2 };
+        for (void** b : bufs) {
+            if (*b) { MIS_HIP(ctx, hipFree(*b)); *b = nullptr; }
+        }
+        w->cap_px = 0;
+        for (void** b : bufs) MIS_HIP(ctx, hipMalloc(b, npx * 4));
+        w->cap_px = npx;
+        w->pair_serial = 0;
+    }
+    if (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H)
+        return MIS_OK;
+    w->pitch = pitch; w->rows = H;
+    dim3 grid((pitch + 255) / 256, H), block(256);
+    hipStream_t s = ctx->stream;
+    for (int side = 0; side < 2; side++) {
+        const void* img = ctx->img[side];
+        if (ctx->dtype == MIS_U8) {
+            const uint8_t* p = (const uint8_t*)img;
+            hipLaunchKernelGGL(ncc_hsum_kernel<uint8_t>, grid, block, 0, s, p, ctx->stride, W, H, r, pitch, w->hs1, w->hs2);
+            if (side == 0)
+                hipLaunchKernelGGL((ncc_stats_kernel<uint8_t, true>), grid, block, 0, s, p, ctx->stride, W, H, r, pitch,
+                                   w->hs1, w->hs2, w->Lpack, w->negc, w->negg, w->iL);
+            else
+                hipLaunchKernelGGL((ncc_stats_kernel<uint8_t, false>), grid, block, 0, s, p, ctx->stride, W, H, r, pitch,
+                                   w->hs1, w->hs2, w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
+        } else {
+            return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: only 8-bit rasters are supported by this build");
+        }
+    }
+    MIS_HIP(ctx, hipGetLastError());
+    w->pair_serial = ctx->pair_serial;
+    w->window = window;
+    return MIS_OK;
+}
+
+template <int R, int WT>
+static int ncc_launch(mis_ctx* ctx, const NccArgs& a, float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
+{
+    const int nstrips = (a.W - 2 * R + WT - 1) / WT;
+    const int nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
+    const int LEN = WT + 2 * R + a.nchunk * 64;
+    const size_t shmem = (size_t)(6 * LEN + 2 * a.nchunk * NFIELD * WT) * 4;
+    dim3 grid(nstrips, nbands), block(a.nchunk * 64);
+    const NccWs* w = ctx->ncc;
+    auto kern = d_peak2 ? ncc_main_kernel<R, WT, true> : ncc_main_kernel<R, WT, false>;
+    if (shmem > 64 * 1024)
+        MIS_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, a, w->Lpack, w->negc, w->negg, w->iL,
+                       w->Rpack, w->Rsr, w->Rir, d_disp, d_peak, d_idisp, d_peak2);
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int nrows,
+                   float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "dense NCC: no image pair bound");
+    if (!d_disp || !d_peak) return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: disp and peak outputs are required");
+    if (window < 3 || window > 31 || !(window & 1)) return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: window %d not odd in 3..31", window);
+    if (dmax < dmin || dmax - dmin + 1 > 2048) return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: bad disparity range [%d,%d]", dmin, dmax);
+    if (dmin < -16000 || dmax > 16000) return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: disparity out of the int16 output range");
+    const int W = ctx->width, H = ctx->height, r = window / 2;
+    if (row0 < 0 || nrows < 0 || row0 + nrows > H) return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: rows [%d,%d) outside the raster", row0, row0 + nrows);
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    if (nrows == 0) return MIS_OK;
+
+    {   // frame border
+        dim3 grid((W + 255) / 256, nrows), block(256);
+        hipLaunchKernelGGL(ncc_border_kernel, grid, block, 0, ctx->stream, d_disp, d_peak, d_idisp, d_peak2, W, H, r, row0, row0 + nrows);
+    }
+    if (W < window || H < window) return MIS_OK;
+    int rc = ncc_prepare(ctx, window);
+    if (rc) return rc;
+
+    NccWs* w = ctx->ncc;
+    NccArgs a;
+    a.W = W; a.H = H; a.pitch = w->pitch;
+    a.dmin = dmin; a.dmax = dmax;
+    a.row0 = row0 > r ? row0 : r;
+    a.row1 = (row0 + nrows < H - r) ? row0 + nrows : H - r;
+    a.out_pitch = W;
+    if (a.row0 >= a.row1) return MIS_OK;
+    const int nd = dmax - dmin + 1;
+    const int total_chunks = (nd + 63) / 64;
+    a.band_rows = 128;
+
+    // a workgroup holds at most 16 wavefronts: wider ranges would need a merge across
+    // workgroups, which this build does not have
+    if (total_chunks > 16) return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: more than 1024 disparities not supported by this build");
+    a.nchunk = total_chunks;
+#define NCC_CASE(RR) case RR: return ncc_launch<RR, 32>(ctx, a, d_disp, d_peak, d_idisp, d_peak2);
+    switch (r) {
+        NCC_CASE(1) NCC_CASE(2) NCC_CASE(3) NCC_CASE(4) NCC_CASE(5) NCC_CASE(6) NCC_CASE(7) NCC_CASE(8)
+        NCC_CASE(9) NCC_CASE(10) NCC_CASE(11) NCC_CASE(12) NCC_CASE(13) NCC_CASE(14) NCC_CASE(15)
+    }
+#undef NCC_CASE
+    return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: unsupported window %d", window);
+}
+
+extern "C" {
+
+int mis_ncc_dense_rows_device(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int nrows,
+                              float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
+{
+    return ncc_run(ctx, window, dmin, dmax, row0, nrows, d_disp, d_peak, d_idisp, d_peak2);
+}
+
+int mis_ncc_dense_device(mis_ctx* ctx, int window, int dmin, int dmax,
+                         float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    return ncc_run(ctx, window, dmin, dmax, 0, ctx->height, d_disp, d_peak, d_idisp, d_peak2);
+}
+
+int mis_ncc_dense(mis_ctx* ctx, int window, int dmin, int dmax,
+                  float* disp, float* peak, int16_t* idisp, float* peak2)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "dense NCC: no image pair bound");
+    if (!disp || !peak) return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: disp and peak outputs are required");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->width * ctx->height;
+    float *dd = nullptr, *dp = nullptr, *dp2 = nullptr; int16_t* di = nullptr;
+    int rc = MIS_OK;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&dd, n * 4)) != hipSuccess || (e = hipMalloc((void**)&dp, n * 4)) != hipSuccess ||
+        (idisp && (e = hipMalloc((void**)&di, n * 2)) != hipSuccess) ||
+        (peak2 && (e = hipMalloc((void**)&dp2, n * 4)) != hipSuccess)) {
+        rc = mis_fail(ctx, MIS_ERR_DEVICE, "dense NCC: output allocation failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) rc = ncc_run(ctx, window, dmin, dmax, 0, ctx->height, dd, dp, di, dp2);
+    if (!rc) {
+        hipStream_t s = ctx->stream;
+        e = hipMemcpyAsync(disp, dd, n * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(peak, dp, n * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && idisp) e = hipMemcpyAsync(idisp, di, n * 2, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && peak2) e = hipMemcpyAsync(peak2, dp2, n * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "dense NCC: copy back failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dd); (void)hipFree(dp); (void)hipFree(di); (void)hipFree(dp2);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,218 @@
+// Ray triangulation of matched points, gfx950: calculateXYZ2 (image3.cpp:102-132) and
+// calculateXYZ (image3.cpp:148-264, FAST_LINE variant), one thread per point, strict float32.
+//
+// This file is compiled with -ffp-contract=off: the reference rounds every product and sum
+// separately (scaleAdd, image3.cpp:110,116), a fused multiply-add would move the 1.0-step search.
+// The camera inverse is hoisted out of the per-point code (the reference recomputes it for every
+// point, image3.cpp:169-172); it is evaluated on the host with the arithmetic OpenCV 2.4 uses for
+// 3x3 CV_32F matrices (cofactors and dot products in double, results narrowed to float).
+#include "mis_common.h"
+
+#include <math.h>
+
+struct TriCam {
+    float Rp[9];   // R^-1
+    float tp[3];   // -R^-1 t
+    float fx, fy, cx, cy;
+};
+
+static void inv3(const float* S, float* D)
+{
+#define Sf(r, c) ((double)S[(r) * 3 + (c)])
+    double d = Sf(0,0) * (Sf(1,1) * Sf(2,2) - Sf(1,2) * Sf(2,1))
+             - Sf(0,1) * (Sf(1,0) * Sf(2,2) - Sf(1,2) * Sf(2,0))
+             + Sf(0,2) * (Sf(1,0) * Sf(2,1) - Sf(1,1) * Sf(2,0));
+    if (d == 0.) { for (int i = 0; i < 9; i++) D[i] = 0.f; return; }
+    d = 1. / d;
+    D[0] = (float)((Sf(1,1) * Sf(2,2) - Sf(1,2) * Sf(2,1)) * d);
+    D[1] = (float)((Sf(0,2) * Sf(2,1) - Sf(0,1) * Sf(2,2)) * d);
+    D[2] = (float)((Sf(0,1) * Sf(1,2) - Sf(0,2) * Sf(1,1)) * d);
+    D[3] = (float)((Sf(1,2) * Sf(2,0) - Sf(1,0) * Sf(2,2)) * d);
+    D[4] = (float)((Sf(0,0) * Sf(2,2) - Sf(0,2) * Sf(2,0)) * d);
+    D[5] = (float)((Sf(0,2) * Sf(1,0) - Sf(0,0) * Sf(1,2)) * d);
+    D[6] = (float)((Sf(1,0) * Sf(2,1) - Sf(1,1) * Sf(2,0)) * d);
+    D[7] = (float)((Sf(0,1) * Sf(2,0) - Sf(0,0) * Sf(2,1)) * d);
+    D[8] = (float)((Sf(0,0) * Sf(1,1) - Sf(0,1) * Sf(1,0)) * d);
+#undef Sf
+}
+
+static TriCam make_cam(const mis_camera* c)
+{
+    TriCam t;
+    inv3(c->R, t.Rp);                                     // image3.cpp:169,171
+    for (int i = 0; i < 3; i++) {                         // image3.cpp:170,172: t' = -R' t
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)t.Rp[i * 3 + k] * (double)c->T[k];
+        t.tp[i] = (float)(s * -1.0);
+    }
+    t.fx = c->A[0]; t.fy = c->A[4]; t.cx = c->A[2]; t.cy = c->A[5];   // image3.cpp:175-183
+    return t;
+}
+
+// image3.cpp:102-132
+__device__ __forceinline__ float xyz2(const float* ang1, const float* t1p, const float* ang2, const float* t2p,
+                                      float z1, float& X, float& Y, float& Z)
+{
+    float w1x = z1 * ang1[0] + t1p[0];
+    float w1y = z1 * ang1[1] + t1p[1];
+    float w1z = z1 * ang1[2] + t1p[2];
+    float z2 = (w1z - t2p[2]) / ang2[2];
+    float w2x = z2 * ang2[0] + t2p[0];
+    float w2y = z2 * ang2[1] + t2p[1];
+    float dx = w1x - w2x, dy = w1y - w2y;
+    float err = __fsqrt_rn(dx * dx + dy * dy);
+    X = w1x; Y = w1y; Z = w1z;
+    return err;
+}
+
+// rotate the pixel ray into world coordinates: gemm with double accumulation (image3.cpp:185-199)
+__device__ __forceinline__ void ray(const TriCam& c, int u, int v, float* ang)
+{
+    float a0 = ((float)u - c.cx) / c.fx;
+    float a1 = -((float)v - c.cy) / c.fy;
+    float a2 = -1.0f;
+    for (int i = 0; i < 3; i++) {
+        double s = (double)c.Rp[i * 3] * (double)a0;
+        s += (double)c.Rp[i * 3 + 1] * (double)a1;
+        s += (double)c.Rp[i * 3 + 2] * (double)a2;
+        ang[i] = (float)s;
+    }
+}
+
+// image3.cpp:148-264 for one point
+__device__ void triangulate_point(const TriCam& c1, const TriCam& c2, int u1, int v1, int u2, int v2,
+                                  float& X, float& Y, float& Z)
+{
+    float ang1[3], ang2[3];
+    ray(c1, u1, v1, ang1);
+    ray(c2, u2, v2, ang2);
+    const float* t1p = c1.tp;
+    const float* t2p = c2.tp;
+    float X1, Y1, Z1;
+    float z0 = 0.0f;
+    float error0 = xyz2(ang1, t1p, ang2, t2p, z0, X, Y, Z);
+    float z1 = 1000.0f;
+    float error1 = xyz2(ang1, t1p, ang2, t2p, z1, X, Y, Z);
+    z0 = z0 + ((z1 - z0) / (error1 - error0) * (0 - error0));          // image3.cpp:216
+    float min_error = error0;
+    int counter = 0;
+    for (z1 = z0; z1 < t1p[2]; z1 += 1.0f) {                             // image3.cpp:220-232
+        float e = xyz2(ang1, t1p, ang2, t2p, z1, X1, Y1, Z1);
+        if (e < min_error) { counter = 0; min_error = e; X = X1; Y = Y1; Z = Z1; }
+        else if (counter++ > 100) break;
+    }
+    counter = 0;
+    for (z1 = z0; z1 > 0; z1 -= 1.0f) {                                  // image3.cpp:233-246
+        float e = xyz2(ang1, t1p, ang2, t2p, z1, X1, Y1, Z1);
+        if (e < min_error) { counter = 0; min_error = e; X = X1; Y = Y1; Z = Z1; }
+        else if (counter++ > 100) break;
+    }
+}
+
+__global__ __launch_bounds__(256) void tri_points_kernel(TriCam c1, TriCam c2, const int4* __restrict__ pts,
+                                                         int n, float* __restrict__ xyz)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int4 p = pts[i];
+    float X, Y, Z;
+    triangulate_point(c1, c2, p.x, p.y, p.z, p.w, X, Y, Z);
+    xyz[3 * (size_t)i] = X; xyz[3 * (size_t)i + 1] = Y; xyz[3 * (size_t)i + 2] = Z;
+}
+
+__global__ __launch_bounds__(256) void tri_disparity_kernel(TriCam c1, TriCam c2, const float* __restrict__ disp,
+                                                            const float* __restrict__ peak, float min_peak,
+                                                            int W, int H, float* __restrict__ xyz,
+                                                            unsigned long long* __restrict__ count)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    bool ok = false;
+    float X = NAN, Y = NAN, Z = NAN;
+    if (x < W) {
+        size_t o = (size_t)y * W + x;
+        float d = disp[o];
+        ok = (d != (float)MIS_INVALID_DISP) && (peak[o] >= min_peak);
+        if (ok) {
+            int u2 = x - (int)rintf(d);
+            triangulate_point(c1, c2, x, y, u2, y, X, Y, Z);
+        }
+        xyz[3 * o] = X; xyz[3 * o + 1] = Y; xyz[3 * o + 2] = Z;
+    }
+    unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+static int tri_check(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!c1 || !c2) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: camera is NULL");
+    return MIS_OK;
+}
+
+extern "C" {
+
+int mis_triangulate_device(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                           const int32_t* d_pts, int n, float* d_xyz)
+{
+    int rc = tri_check(ctx, c1, c2);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!d_pts || !d_xyz))) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: bad point buffers");
+    if (n == 0) return MIS_OK;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    TriCam a = make_cam(c1), b = make_cam(c2);
+    hipLaunchKernelGGL(tri_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a, b,
+                       (const int4*)d_pts, n, d_xyz);
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+int mis_triangulate(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                    const int32_t* pts, int n, float* xyz)
+{
+    int rc = tri_check(ctx, c1, c2);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!pts || !xyz))) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: bad point buffers");
+    if (n == 0) return MIS_OK;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    size_t need = (size_t)n * 16 + (size_t)n * 12;
+    rc = mis_reserve(ctx, &ctx->tri_buf, &ctx->tri_bytes, need);
+    if (rc) return rc;
+    int32_t* dp = (int32_t*)ctx->tri_buf;
+    float* dx = (float*)((char*)ctx->tri_buf + (size_t)n * 16);
+    MIS_HIP(ctx, hipMemcpyAsync(dp, pts, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    rc = mis_triangulate_device(ctx, c1, c2, dp, n, dx);
+    if (rc) return rc;
+    MIS_HIP(ctx, hipMemcpyAsync(xyz, dx, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MIS_OK;
+}
+
+int mis_triangulate_disparity_device(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                                     const float* d_disp, const float* d_peak, float min_peak,
+                                     float* d_xyz, long long* n_matched)
+{
+    int rc = tri_check(ctx, c1, c2);
+    if (rc) return rc;
+    if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "triangulate: no image pair bound (raster size unknown)");
+    if (!d_disp || !d_peak || !d_xyz) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: NULL buffer");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    rc = mis_reserve(ctx, &ctx->tri_buf, &ctx->tri_bytes, 256);
+    if (rc) return rc;
+    unsigned long long* cnt = (unsigned long long*)ctx->tri_buf;
+    MIS_HIP(ctx, hipMemsetAsync(cnt, 0, 256, ctx->stream));
+    TriCam a = make_cam(c1), b = make_cam(c2);
+    const int W = ctx->width, H = ctx->height;
+    hipLaunchKernelGGL(tri_disparity_kernel, dim3((W + 255) / 256, H), dim3(256), 0, ctx->stream, a, b,
+                       d_disp, d_peak, min_peak, W, H, d_xyz, cnt);
+    MIS_HIP(ctx, hipGetLastError());
+    if (n_matched) {
+        unsigned long long h = 0;
+        MIS_HIP(ctx, hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *n_matched = (long long)h;
+    }
+    return MIS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+"""ctypes binding of libmistereo.so (include/mi_stereo.h) for tests, bench.py and Python hosts.
+
+The library is the product; this module is plumbing.  It mirrors the reference's call sites:
+``find_offset`` <-> findOffset (image3.cpp:346), ``calculate_xyz`` <-> calculateXYZ
+(image3.cpp:272), ``fft2d_forward`` <-> image-fft.cpp CalcFFT, ``xcorr_surface_u8`` <->
+image-cross-cor.cpp CalcFFT, ``ncc_dense`` <-> the dense mode of image3.cpp:775-811, 866-870.
+
+There is no CPU fallback: importing works anywhere, but ``Context()`` raises unless the HIP
+library is present and a gfx950 device is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmistereo.so")
+
+U8, U16, F32 = 0, 1, 2
+INVALID_DISP = -32768
+
+
+class Rect(C.Structure):
+    """struct Rect of image3.cpp:77-82."""
+    _fields_ = [("minx", C.c_int32), ("miny", C.c_int32), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Offset(C.Structure):
+    _fields_ = [("dx", C.c_int32), ("dy", C.c_int32), ("peak", C.c_float), ("dog_peak", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("A", C.c_float * 9), ("R", C.c_float * 9), ("T", C.c_float * 3)]
+
+
+class MisError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libmistereo error %d: %s" % (code, msg))
+        self.code = code
+
+
+EXPORTS = [
+    "mis_create", "mis_destroy", "mis_last_error", "mis_set_stream", "mis_synchronize",
+    "mis_upload_pair", "mis_bind_pair_device",
+    "mis_ncc_dense", "mis_ncc_dense_device", "mis_ncc_dense_rows_device",
+    "mis_xcorr_tiles", "mis_xcorr_tiles_device", "mis_xcorr_tile_surfaces",
+    "mis_fft2d_forward", "mis_xcorr_surface_u8",
+    "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
+    "mis_version",
+]
+
+_lib = None
+
+
+def load_library():
+    """Load libmistereo.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmistereo.so is missing (%s): build it with `make -C image-processing_amd`; "
+                              "there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.mis_last_error.restype = C.c_char_p
+        lib.mis_last_error.argtypes = [C.c_void_p]
+        lib.mis_version.restype = C.c_char_p
+        vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+        lib.mis_create.argtypes = [i32, C.POINTER(vp)]
+        lib.mis_destroy.argtypes = [vp]
+        lib.mis_set_stream.argtypes = [vp, vp]
+        lib.mis_synchronize.argtypes = [vp]
+        lib.mis_upload_pair.argtypes = [vp, vp, vp, i32, i32, i32, sz]
+        lib.mis_bind_pair_device.argtypes = [vp, vp, vp, i32, i32, i32, sz]
+        lib.mis_ncc_dense.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+        lib.mis_ncc_dense_device.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+        lib.mis_ncc_dense_rows_device.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+        lib.mis_xcorr_tiles.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+        lib.mis_xcorr_tiles_device.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+        lib.mis_xcorr_tile_surfaces.argtypes = [vp, Rect, Rect, i32, i32, vp, vp]
+        lib.mis_fft2d_forward.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+        lib.mis_xcorr_surface_u8.argtypes = [vp, vp]
+        lib.mis_triangulate.argtypes = [vp, vp, vp, vp, i32, vp]
+        lib.mis_triangulate_device.argtypes = [vp, vp, vp, vp, i32, vp]
+        lib.mis_triangulate_disparity_device.argtypes = [vp, vp, vp, vp, vp, f32, vp, vp]
+        _lib = lib
+    return _lib
+
+
+def _dtype_code(dt):
+    dt = np.dtype(dt)
+    if dt == np.uint8:
+        return U8
+    if dt == np.uint16:
+        return U16
+    if dt == np.float32:
+        return F32
+    raise TypeError("unsupported pixel type %s" % dt)
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _dev_ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def make_camera(A, R, T):
+    cam = Camera()
+    cam.A[:] = [float(v) for v in np.asarray(A, np.float32).reshape(9)]
+    cam.R[:] = [float(v) for v in np.asarray(R, np.float32).reshape(9)]
+    cam.T[:] = [float(v) for v in np.asarray(T, np.float32).reshape(3)]
+    return cam
+
+
+def _rects(rects):
+    arr = np.ascontiguousarray(rects, np.int32).reshape(-1, 4)
+    return arr
+
+
+class Context:
+    """One context per GPU and host thread; owns device scratch (mis_create / mis_destroy)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.mis_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise MisError(rc, self._lib.mis_last_error(None).decode())
+        self.shape = None
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            self._lib.mis_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MisError(rc, self._lib.mis_last_error(self._h).decode())
+
+    # ---- plumbing ----
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.mis_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def synchronize(self):
+        self._check(self._lib.mis_synchronize(self._h))
+
+    # ---- image pair ----
+    def upload_pair(self, img1, img2):
+        img1 = np.ascontiguousarray(img1)
+        img2 = np.ascontiguousarray(img2)
+        if img1.shape != img2.shape or img1.dtype != img2.dtype or img1.ndim != 2:
+            raise ValueError("image pair must be two 2-D rasters of equal shape and type")
+        h, w = img1.shape
+        self._check(self._lib.mis_upload_pair(self._h, _np_ptr(img1), _np_ptr(img2), _dtype_code(img1.dtype),
+                                              w, h, img1.strides[0]))
+        self.shape = (h, w)
+        self._keep = None
+
+    def bind_pair_torch(self, t1, t2):
+        """Bind two 2-D CUDA tensors (uint8 / uint16-as-int16 storage is not supported: use uint8,
+        torch.uint16 or float32) without copying; the tensors are kept alive by the context."""
+        import torch
+        if t1.shape != t2.shape or t1.dtype != t2.dtype or t1.dim() != 2 or not t1.is_cuda:
+            raise ValueError("need two 2-D CUDA tensors of equal shape and type")
+        code = {torch.uint8: U8, torch.uint16: U16, torch.float32: F32}[t1.dtype]
+        if t1.stride(1) != 1 or t2.stride(1) != 1 or t1.stride(0) != t2.stride(0):
+            raise ValueError("rows must be contiguous with equal strides")
+        h, w = t1.shape
+        self._check(self._lib.mis_bind_pair_device(self._h, _dev_ptr(t1), _dev_ptr(t2), code, w, h,
+                                                   t1.stride(0) * t1.element_size()))
+        self.shape = (h, w)
+        self._keep = (t1, t2)
+
+    # ---- dense NCC ----
+    def ncc_dense(self, window, dmin, dmax, want_idisp=True, want_peak2=False):
+        h, w = self.shape
+        disp = np.empty((h, w), np.float32)
+        peak = np.empty((h, w), np.float32)
+        idisp = np.empty((h, w), np.int16) if want_idisp else None
+        peak2 = np.empty((h, w), np.float32) if want_peak2 else None
+        self._check(self._lib.mis_ncc_dense(self._h, window, dmin, dmax, _np_ptr(disp), _np_ptr(peak),
+                                            _np_ptr(idisp), _np_ptr(peak2)))
+        out = {"disp": disp, "peak": peak}
+        if want_idisp:
+            out["idisp"] = idisp
+        if want_peak2:
+            out["peak2"] = peak2
+        return out
+
+    def ncc_dense_torch(self, window, dmin, dmax, disp, peak, idisp=None, peak2=None, row0=None, nrows=None):
+        """Enqueue on the context's stream; outputs are CUDA tensors of the frame's shape."""
+        if row0 is None:
+            self._check(self._lib.mis_ncc_dense_device(self._h, window, dmin, dmax, _dev_ptr(disp), _dev_ptr(peak),
+                                                       _dev_ptr(idisp), _dev_ptr(peak2)))
+        else:
+            self._check(self._lib.mis_ncc_dense_rows_device(self._h, window, dmin, dmax, row0, nrows,
+                                                            _dev_ptr(disp), _dev_ptr(peak), _dev_ptr(idisp),
+                                                            _dev_ptr(peak2)))
+
+    # ---- FFT tile correlation ----
+    def find_offsets(self, rects1, rects2, tile_w, tile_h):
+        """Batched findOffset (image3.cpp:346): returns arrays dx, dy, peak, dog_peak."""
+        r1, r2 = _rects(rects1), _rects(rects2)
+        if r1.shape != r2.shape:
+            raise ValueError("rect lists differ in length")
+        n = r1.shape[0]
+        out = (Offset * n)()
+        self._check(self._lib.mis_xcorr_tiles(self._h, _np_ptr(r1), _np_ptr(r2), n, tile_w, tile_h, out))
+        res = np.frombuffer(out, dtype=[("dx", "<i4"), ("dy", "<i4"), ("peak", "<f4"), ("dog_peak", "<f4")])
+        return res.copy()
+
+    def find_offset(self, bbox1, bbox2, width, height):
+        """findOffset(bbox1, bbox2, width, height, &ox, &oy) -> (peak, ox, oy)."""
+        r = self.find_offsets([bbox1], [bbox2], width, height)[0]
+        return float(r["peak"]), int(r["dx"]), int(r["dy"])
+
+    def tile_surfaces(self, bbox1, bbox2, width, height):
+        surf = np.empty((height, width), np.float32)
+        dog = np.empty((height, width), np.float32)
+        self._check(self._lib.mis_xcorr_tile_surfaces(self._h, Rect(*bbox1), Rect(*bbox2), width, height,
+                                                      _np_ptr(surf), _np_ptr(dog)))
+        return surf, dog
+
+    def fft2d_forward(self, imgs):
+        """image-fft.cpp CalcFFT for a batch of rasters [batch, h, w] (or one [h, w])."""
+        a = np.ascontiguousarray(imgs)
+        single = a.ndim == 2
+        if single:
+            a = a[None]
+        b, h, w = a.shape
+        out = np.empty((b, h, w), np.complex64)
+        self._check(self._lib.mis_fft2d_forward(self._h, _np_ptr(a), _dtype_code(a.dtype), w, h, b, _np_ptr(out)))
+        return out[0] if single else out
+
+    def xcorr_surface_u8(self):
+        h, w = self.shape
+        out = np.empty((h, w), np.uint8)
+        self._check(self._lib.mis_xcorr_surface_u8(self._h, _np_ptr(out)))
+        return out
+
+    # ---- triangulation ----
+    def calculate_xyz(self, cam1, cam2, pts):
+        """calculateXYZ (image3.cpp:148-264) for rows of (u1, v1, u2, v2)."""
+        p = np.ascontiguousarray(pts, np.int32).reshape(-1, 4)
+        out = np.empty((p.shape[0], 3), np.float32)
+        self._check(self._lib.mis_triangulate(self._h, C.byref(cam1), C.byref(cam2), _np_ptr(p), p.shape[0],
+                                              _np_ptr(out)))
+        return out
+
+    def triangulate_disparity_torch(self, cam1, cam2, disp, peak, min_peak, xyz, count=True):
+        n = C.c_longlong(0)
+        self._check(self._lib.mis_triangulate_disparity_device(self._h, C.byref(cam1), C.byref(cam2), _dev_ptr(disp),
+                                                               _dev_ptr(peak), C.c_float(min_peak), _dev_ptr(xyz),
+                                                               C.byref(n) if count else None))
+        return n.value if count else None

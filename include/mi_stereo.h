@@ -1,0 +1,142 @@
+/*
+ * mi_stereo.h -- C ABI of libmistereo.so, the MI355X (gfx950) stereo-correlation library.
+ *
+ * Drop-in boundary for the hot path of klassenjs/image-processing.  The reference has no
+ * plugin or FFI layer: its programs call static functions that reach the rasters through
+ * globals.  Each entry point below names the reference function it replaces (file:line in
+ * the reference tree); the host program keeps raster I/O, bookkeeping and output files.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (MIS_OK == 0), never throws;
+ *     mis_last_error(ctx) returns the message of the last failure on that context
+ *   - the caller owns every buffer it passes in; the context owns device scratch
+ *   - calls on one context are serialised by the caller; contexts are independent
+ *   - "_device" entry points take device pointers and only enqueue work on the context's
+ *     stream (mis_set_stream); the others take host pointers and return when results are in
+ *     host memory
+ *   - there is no CPU fallback: without a usable HIP device mis_create fails
+ */
+#ifndef MI_STEREO_H
+#define MI_STEREO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIS_OK 0
+#define MIS_ERR_ARG 1        /* invalid argument */
+#define MIS_ERR_DEVICE 2     /* HIP runtime failure */
+#define MIS_ERR_UNSUPPORTED 3
+#define MIS_ERR_STATE 4      /* call sequence error (e.g. no image pair bound) */
+
+/* pixel types of rasters handed to the library (GDAL Byte / UInt16 / Float32) */
+#define MIS_U8 0
+#define MIS_U16 1
+#define MIS_F32 2
+
+/* value written to disparity outputs where no correlation window fits */
+#define MIS_INVALID_DISP (-32768)
+
+typedef struct mis_ctx mis_ctx;
+
+/* image3.cpp:77-82 (struct Rect) */
+typedef struct { int32_t minx, miny, width, height; } mis_rect;
+
+/* result of one tile correlation: what findOffset returns through *offset_x, *offset_y and
+ * its return value (image3.cpp:507-516), plus the DoG value at the peak (image3.cpp:495) */
+typedef struct { int32_t dx, dy; float peak; float dog_peak; } mis_offset;
+
+/* camera read from "<image>.yaml": A (intrinsics), R, T as CV_32F (image3.cpp:1014-1030) */
+typedef struct { float A[9]; float R[9]; float T[3]; } mis_camera;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* Replaces the per-call fftwf_malloc / fftwf_plan_dft_2d / free of image3.cpp:357-372, 421-425
+ * and the process globals of image3.cpp:340-344: buffers, twiddles and the blur kernel live
+ * in the context. */
+int mis_create(int device_id, mis_ctx** out);
+int mis_destroy(mis_ctx* ctx);
+const char* mis_last_error(const mis_ctx* ctx);   /* ctx may be NULL: last mis_create error */
+/* hipStream_t as void*; NULL selects the context's own stream (the default) */
+int mis_set_stream(mis_ctx* ctx, void* hip_stream);
+int mis_synchronize(mis_ctx* ctx);
+
+/* ---- image pair ------------------------------------------------------------------------ */
+/* Replaces the GDALOpen'ed srcDS1/srcDS2 globals and the RasterIO reads inside the hot loop
+ * (image3.cpp:325-328, 979-980): the pair is copied to HBM once. */
+int mis_upload_pair(mis_ctx* ctx, const void* img1, const void* img2, int dtype,
+                    int width, int height, size_t row_stride_bytes);
+/* Same, for rasters already in device memory (not copied; must stay valid while bound). */
+int mis_bind_pair_device(mis_ctx* ctx, const void* d_img1, const void* d_img2, int dtype,
+                         int width, int height, size_t row_stride_bytes);
+
+/* ---- dense windowed NCC ------------------------------------------------------------------
+ * The dense per-pixel mode the reference leaves disabled (image3.cpp:775-811) and lists as a
+ * TODO (image3.cpp:866-870): for every pixel of image 1, zero-mean normalised correlation of
+ * the window x window patch against image 2 at horizontal offsets d in [dmin,dmax] (image-1
+ * position = image-2 position + d, the sign of image3.cpp:696-699), first maximum wins
+ * (image3.cpp:486-501), parabolic subpixel refinement.
+ *   disp   float  disparity with subpixel part, MIS_INVALID_DISP where no window fits
+ *   peak   float  NCC at the integer maximum (0 where invalid)
+ *   idisp  int16  integer maximum (nullable)
+ *   peak2  float  best NCC further than 1 px from the maximum, -1 if none (nullable)
+ * u8 and u16 rasters; window odd, 3..31; 1 <= dmax-dmin+1 <= 2048. */
+int mis_ncc_dense(mis_ctx* ctx, int window, int dmin, int dmax,
+                  float* disp, float* peak, int16_t* idisp, float* peak2);
+int mis_ncc_dense_device(mis_ctx* ctx, int window, int dmin, int dmax,
+                         float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2);
+/* Row-strip form used when a frame is split over GPUs: only output rows [row0, row0+nrows)
+ * are computed and written (outputs are still addressed as full frames). */
+int mis_ncc_dense_rows_device(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int nrows,
+                              float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2);
+
+/* ---- FFT tile correlation ------------------------------------------------------------------
+ * Batched findOffset (image3.cpp:346-517 with runFFT image3.cpp:318-335): for each i, the
+ * tile r1[i] of image 1 and r2[i] of image 2, zero-padded to tile_w x tile_h, are correlated
+ * over all circular shifts; the |c| surface is min-max normalised, the 151-tap sigma-99
+ * Gaussian is subtracted and the first maximum of the difference gives (dx,dy).
+ * tile_w, tile_h: powers of two, 16..8192. */
+int mis_xcorr_tiles(mis_ctx* ctx, const mis_rect* r1, const mis_rect* r2, int n,
+                    int tile_w, int tile_h, mis_offset* out);
+int mis_xcorr_tiles_device(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, int n,
+                           int tile_w, int tile_h, mis_offset* d_out);
+/* Debug/inspection: normalised surface (image3.cpp:414-416) and DoG image (image3.cpp:483) of
+ * one tile, tile_w*tile_h floats each, host memory, either may be NULL. */
+int mis_xcorr_tile_surfaces(mis_ctx* ctx, mis_rect r1, mis_rect r2, int tile_w, int tile_h,
+                            float* surface, float* dog);
+
+/* image-fft.cpp:45-105 (CalcFFT): forward 2-D DFT of `batch` real rasters of w x h pixels
+ * (contiguous, row stride w), each value divided by sqrt(w*h); out: batch*w*h complex64
+ * (interleaved re,im).  Host pointers.  w, h powers of two. */
+int mis_fft2d_forward(mis_ctx* ctx, const void* in, int dtype, int w, int h, int batch,
+                      float* out_complex);
+
+/* image-cross-cor.cpp:104-186 (CalcFFT) for the bound pair: whole-image correlation surface
+ * quantised floor(v*255) and fft-shifted (image-cross-cor.cpp:166-170).  out: w*h bytes, host.
+ * Image size must be a power of two in both dimensions. */
+int mis_xcorr_surface_u8(mis_ctx* ctx, uint8_t* out);
+
+/* ---- triangulation -------------------------------------------------------------------------
+ * calculateXYZ (image3.cpp:148-264, wrapper 272-280) for n points; pts = n x (u1,v1,u2,v2),
+ * xyz = n x (X,Y,Z), float32 throughout. */
+int mis_triangulate(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                    const int32_t* pts, int n, float* xyz);
+int mis_triangulate_device(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                           const int32_t* d_pts, int n, float* d_xyz);
+/* Dense form: one point per pixel of a disparity raster produced by mis_ncc_dense:
+ * (u1,v1) = (x,y), (u2,v2) = (x - round(disp), y); pixels with peak < min_peak or invalid
+ * disparity get NaN.  d_xyz: height*width*3 floats.  Returns the matched count in *n_matched
+ * (nullable; reading it synchronises the stream). */
+int mis_triangulate_disparity_device(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                                     const float* d_disp, const float* d_peak, float min_peak,
+                                     float* d_xyz, long long* n_matched);
+
+/* library build information: "gfx950 <git describe or date>" */
+const char* mis_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

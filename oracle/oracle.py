@@ -1,0 +1,202 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the
+product path (image-processing_amd/) never does.  PARITY UNPINNED: see oracle/oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+U8, U16, F32 = 0, 1, 2
+INVALID_DISP = -32768
+
+
+class Rect(C.Structure):
+    _fields_ = [("minx", C.c_int), ("miny", C.c_int), ("width", C.c_int), ("height", C.c_int)]
+
+
+class Offset(C.Structure):
+    _fields_ = [("dx", C.c_int), ("dy", C.c_int), ("peak", C.c_float), ("dog_peak", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("A", C.c_float * 9), ("R", C.c_float * 9), ("T", C.c_float * 3)]
+
+
+class Leaf(C.Structure):
+    _fields_ = [("bbox1", Rect), ("total_dx", C.c_int), ("total_dy", C.c_int),
+                ("u1", C.c_int), ("v1", C.c_int), ("u2", C.c_int), ("v2", C.c_int),
+                ("peak", C.c_float)]
+
+
+def build(force=False):
+    """Compile liboracle.so from the C sources next to this file."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_ncc_score.restype = C.c_double
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _dtype_code(a):
+    if a.dtype == np.uint8:
+        return U8
+    if a.dtype == np.uint16:
+        return U16
+    if a.dtype == np.float32:
+        return F32
+    raise TypeError("unsupported pixel type %s" % a.dtype)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_camera(A, R, T):
+    cam = Camera()
+    cam.A[:] = [float(v) for v in np.asarray(A, np.float32).reshape(9)]
+    cam.R[:] = [float(v) for v in np.asarray(R, np.float32).reshape(9)]
+    cam.T[:] = [float(v) for v in np.asarray(T, np.float32).reshape(3)]
+    return cam
+
+
+def ncc_dense(left, right, window, dmin, dmax, want_peak2=False, want_volume=False):
+    left = np.ascontiguousarray(left)
+    right = np.ascontiguousarray(right)
+    assert left.shape == right.shape and left.dtype == right.dtype
+    h, w = left.shape
+    disp = np.empty((h, w), np.float32)
+    peak = np.empty((h, w), np.float32)
+    idisp = np.empty((h, w), np.int16)
+    peak2 = np.empty((h, w), np.float32) if want_peak2 else None
+    vol = np.empty((h, w, dmax - dmin + 1), np.float64) if want_volume else None
+    rc = lib().orc_ncc_dense(_ptr(left), _ptr(right), _dtype_code(left), w, h,
+                             C.c_size_t(left.strides[0]), window, dmin, dmax,
+                             _ptr(disp), _ptr(peak), _ptr(idisp), _ptr(peak2), _ptr(vol))
+    if rc != 0:
+        raise ValueError("orc_ncc_dense rejected its arguments")
+    out = {"disp": disp, "peak": peak, "idisp": idisp}
+    if want_peak2:
+        out["peak2"] = peak2
+    if want_volume:
+        out["volume"] = vol
+    return out
+
+
+def ncc_score(left, right, window, x, y, d):
+    left = np.ascontiguousarray(left)
+    right = np.ascontiguousarray(right)
+    h, w = left.shape
+    return lib().orc_ncc_score(_ptr(left), _ptr(right), _dtype_code(left), w, h,
+                               C.c_size_t(left.strides[0]), window, int(x), int(y), int(d))
+
+
+def fft2d(data, sign, double=True):
+    """In-place-style 2-D DFT of a complex array (unnormalised); returns a new array."""
+    if double:
+        a = np.ascontiguousarray(data, np.complex128).copy()
+        lib().orc_fft2d_f64(_ptr(a), a.shape[1], a.shape[0], int(sign))
+    else:
+        a = np.ascontiguousarray(data, np.complex64).copy()
+        lib().orc_fft2d_f32(_ptr(a), a.shape[1], a.shape[0], int(sign))
+    return a
+
+
+def fft2d_forward(img):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.complex64)
+    lib().orc_fft2d_forward(_ptr(img), _dtype_code(img), w, h, C.c_size_t(img.strides[0]), _ptr(out))
+    return out
+
+
+def find_offset(img1, img2, b1, b2, width, height, precision=0, want_surface=False, want_dog=False):
+    img1 = np.ascontiguousarray(img1)
+    img2 = np.ascontiguousarray(img2)
+    assert img1.dtype == img2.dtype
+    r1, r2 = Rect(*b1), Rect(*b2)
+    off = Offset()
+    surf = np.empty((height, width), np.float32) if want_surface else None
+    dog = np.empty((height, width), np.float32) if want_dog else None
+    lib().orc_find_offset(_ptr(img1), img1.shape[1], img1.shape[0], C.c_size_t(img1.strides[0]),
+                          _ptr(img2), img2.shape[1], img2.shape[0], C.c_size_t(img2.strides[0]),
+                          _dtype_code(img1), r1, r2, width, height, precision, C.byref(off),
+                          _ptr(surf), _ptr(dog))
+    res = {"dx": off.dx, "dy": off.dy, "peak": off.peak, "dog_peak": off.dog_peak}
+    if want_surface:
+        res["surface"] = surf
+    if want_dog:
+        res["dog"] = dog
+    return res
+
+
+def gaussian_blur(src, ksize=151, sigma=99.0):
+    src = np.ascontiguousarray(src, np.float32)
+    dst = np.empty_like(src)
+    lib().orc_gaussian_blur(_ptr(src), _ptr(dst), src.shape[1], src.shape[0], ksize, C.c_double(sigma))
+    return dst
+
+
+def xcorr_surface_u8(img1, img2, precision=0):
+    img1 = np.ascontiguousarray(img1)
+    img2 = np.ascontiguousarray(img2)
+    h, w = img1.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_xcorr_surface_u8(_ptr(img1), _ptr(img2), _dtype_code(img1), w, h,
+                               C.c_size_t(img1.strides[0]), precision, _ptr(out))
+    return out
+
+
+def fft2shift(a):
+    a = np.ascontiguousarray(a).copy()
+    if a.dtype == np.float32:
+        lib().orc_fft2shift_f32(_ptr(a), a.shape[1], a.shape[0])
+    elif a.dtype == np.uint8:
+        lib().orc_fft2shift_u8(_ptr(a), a.shape[0], a.shape[1])
+    else:
+        raise TypeError(a.dtype)
+    return a
+
+
+def triangulate(cam1, cam2, pts):
+    pts = np.ascontiguousarray(pts, np.int32).reshape(-1, 4)
+    out = np.empty((pts.shape[0], 3), np.float32)
+    lib().orc_triangulate(C.byref(cam1), C.byref(cam2), _ptr(pts), pts.shape[0], _ptr(out))
+    return out
+
+
+def disparity_map(img1, img2, min_size=32, precision=0, max_leaves=1 << 16):
+    img1 = np.ascontiguousarray(img1)
+    img2 = np.ascontiguousarray(img2)
+    h, w = img1.shape
+    leaves = (Leaf * max_leaves)()
+    ncalls = C.c_int(0)
+    n = lib().orc_disparity_map(_ptr(img1), _ptr(img2), _dtype_code(img1), w, h,
+                                C.c_size_t(img1.strides[0]), min_size, precision,
+                                leaves, max_leaves, C.byref(ncalls))
+    if n < 0:
+        raise RuntimeError("no overlap")
+    recs = [(l.bbox1.minx, l.bbox1.miny, l.bbox1.width, l.bbox1.height, l.total_dx, l.total_dy,
+             l.u1, l.v1, l.u2, l.v2, l.peak) for l in leaves[:min(n, max_leaves)]]
+    return recs, ncalls.value
+
+
+def num_threads():
+    return lib().orc_num_threads()

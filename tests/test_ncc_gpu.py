@@ -1,0 +1,61 @@
+"""Dense-NCC parity: libmistereo (HIP, through the C ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle
+import synth
+from ncc_util import compare_ncc, flat_mask
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, left, right, window, dmin, dmax, peak2=False):
+    ctx.upload_pair(left, right)
+    gpu = ctx.ncc_dense(window, dmin, dmax, want_idisp=True, want_peak2=peak2)
+    ora = oracle.ncc_dense(left, right, window, dmin, dmax, want_peak2=peak2, want_volume=True)
+    ora["flat"] = flat_mask(ora["volume"], ora["idisp"], dmin)
+    return compare_ncc(gpu, ora, volume=ora["volume"], dmin=dmin, check_peak2=peak2)
+
+
+@pytest.mark.parametrize("window,dmin,dmax,shape,shift", [
+    (15, -64, 64, (96, 300), 17),
+    (21, -40, 90, (80, 260), -23),
+    (3, -5, 5, (40, 70), 2),
+    (31, -70, 70, (70, 256), 40),
+    (7, 0, 63, (50, 200), 11),       # exactly one chunk
+    (9, -100, 27, (64, 333), -60),   # two chunks, ragged width
+])
+def test_constant_shift(ctx, window, dmin, dmax, shape, shift):
+    left = synth.texture(shape[0], shape[1], 1234 + window)
+    right = synth.shift_right_image(left, shift, fill_seed=99)
+    st = _run(ctx, left, right, window, dmin, dmax)
+    assert st["valid"] > 0
+
+
+def test_peak2(ctx):
+    left = synth.texture(72, 280, 77)
+    right = synth.shift_right_image(left, 9, fill_seed=5)
+    _run(ctx, left, right, 11, -70, 70, peak2=True)
+
+
+def test_piecewise_disparity_with_noise(ctx):
+    left, right, p = synth.config_pair(2, h=120, w=700)
+    _run(ctx, left, right, p["window"], -130, 130)
+
+
+def test_flat_and_saturated_regions(ctx):
+    rng = np.random.default_rng(3)
+    left = synth.texture(90, 320, 5)
+    left[20:60, 100:180] = 200          # flat patch: zero variance windows
+    left[:, 250:] = 255
+    left[70:, :40] = 0
+    right = synth.shift_right_image(left, 6, fill_seed=8)
+    right[30:50, 10:90] = rng.integers(0, 2, (20, 80)) * 255   # extreme contrast
+    _run(ctx, left, right, 15, -32, 32)
+
+
+def test_too_small_frame_is_all_invalid(ctx):
+    left = synth.texture(10, 40, 1)
+    ctx.upload_pair(left, left)
+    out = ctx.ncc_dense(15, -4, 4)
+    assert np.all(out["idisp"] == -32768) and np.all(out["peak"] == 0)
