@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <vector>
 
 #include "mi_stereo.h"
 
@@ -26,6 +27,11 @@ struct mis_ctx {
     struct NccWs* ncc = nullptr;
     // FFT-correlation workspace (see xcorr_kernels.hip)
     struct XcorrWs* xc = nullptr;
+    // optional per-call device timing of the dense-NCC kernels (mis_profile_*)
+    bool profile = false;
+    std::vector<hipEvent_t> prof_events;   // triples: start, main kernel start, main kernel end
+    size_t prof_used = 0;                  // events handed out since the last read
+
     // triangulation scratch
     void* tri_buf = nullptr; size_t tri_bytes = 0;
 };
@@ -41,6 +47,9 @@ int mis_fail(mis_ctx* ctx, int code, const char* fmt, ...);
 
 // grows *buf to at least `bytes` (device memory); contents are not preserved
 int mis_reserve(mis_ctx* ctx, void** buf, size_t* cap, size_t bytes);
+
+// next event of the profiling pool, recorded on the context's stream (nullptr: profiling off)
+hipEvent_t mis_prof_mark(mis_ctx* ctx);
 
 void mis_ncc_release(mis_ctx* ctx);
 void mis_xcorr_release(mis_ctx* ctx);

@@ -34,7 +34,48 @@ int mis_reserve(mis_ctx* ctx, void** buf, size_t* cap, size_t bytes)
     return MIS_OK;
 }
 
+hipEvent_t mis_prof_mark(mis_ctx* ctx)
+{
+    if (!ctx->profile) return nullptr;
+    if (ctx->prof_used == ctx->prof_events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ctx->prof_events.push_back(e);
+    }
+    hipEvent_t e = ctx->prof_events[ctx->prof_used++];
+    (void)hipEventRecord(e, ctx->stream);
+    return e;
+}
+
 extern "C" {
+
+int mis_profile_enable(mis_ctx* ctx, int on)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    ctx->profile = on != 0;
+    ctx->prof_used = 0;
+    return MIS_OK;
+}
+
+int mis_profile_read(mis_ctx* ctx, double* prepass_ms, double* main_ms, int* calls)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double pre = 0, mainv = 0;
+    int n = 0;
+    for (size_t i = 0; i + 2 < ctx->prof_used && i + 2 < ctx->prof_events.size(); i += 3) {
+        float a = 0, b = 0;
+        MIS_HIP(ctx, hipEventElapsedTime(&a, ctx->prof_events[i], ctx->prof_events[i + 1]));
+        MIS_HIP(ctx, hipEventElapsedTime(&b, ctx->prof_events[i + 1], ctx->prof_events[i + 2]));
+        pre += a; mainv += b; n++;
+    }
+    ctx->prof_used = 0;
+    if (prepass_ms) *prepass_ms = pre;
+    if (main_ms) *main_ms = mainv;
+    if (calls) *calls = n;
+    return MIS_OK;
+}
 
 const char* mis_version(void) { return "libmistereo gfx950 " __DATE__; }
 
@@ -69,13 +110,14 @@ int mis_create(int device_id, mis_ctx** out)
 int mis_destroy(mis_ctx* ctx)
 {
     if (!ctx) return MIS_OK;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
     mis_ncc_release(ctx);
     mis_xcorr_release(ctx);
-    if (ctx->tri_buf) hipFree(ctx->tri_buf);
-    for (int i = 0; i < 2; i++) if (ctx->owned_img[i]) hipFree(ctx->owned_img[i]);
-    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    if (ctx->tri_buf) (void)hipFree(ctx->tri_buf);
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; i++) if (ctx->owned_img[i]) (void)hipFree(ctx->owned_img[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MIS_OK;
 }

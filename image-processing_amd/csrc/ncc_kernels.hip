@@ -508,13 +508,15 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     if (nrows == 0) return MIS_OK;
 
+    mis_prof_mark(ctx);
     {   // frame border
         dim3 grid((W + 255) / 256, nrows), block(256);
         hipLaunchKernelGGL(ncc_border_kernel, grid, block, 0, ctx->stream, d_disp, d_peak, d_idisp, d_peak2, W, H, r, row0, row0 + nrows);
     }
-    if (W < window || H < window) return MIS_OK;
+    if (W < window || H < window) { mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
     int rc = ncc_prepare(ctx, window);
     if (rc) return rc;
+    mis_prof_mark(ctx);
 
     NccWs* w = ctx->ncc;
     NccArgs a;
@@ -523,7 +525,7 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     a.row0 = row0 > r ? row0 : r;
     a.row1 = (row0 + nrows < H - r) ? row0 + nrows : H - r;
     a.out_pitch = W;
-    if (a.row0 >= a.row1) return MIS_OK;
+    if (a.row0 >= a.row1) { mis_prof_mark(ctx); return MIS_OK; }
     const int nd = dmax - dmin + 1;
     const int total_chunks = (nd + 63) / 64;
     a.band_rows = 128;
@@ -532,13 +534,15 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     // workgroups, which this build does not have
     if (total_chunks > 16) return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: more than 1024 disparities not supported by this build");
     a.nchunk = total_chunks;
-#define NCC_CASE(RR) case RR: return ncc_launch<RR, 32>(ctx, a, d_disp, d_peak, d_idisp, d_peak2);
+#define NCC_CASE(RR) case RR: rc = ncc_launch<RR, 32>(ctx, a, d_disp, d_peak, d_idisp, d_peak2); break;
     switch (r) {
         NCC_CASE(1) NCC_CASE(2) NCC_CASE(3) NCC_CASE(4) NCC_CASE(5) NCC_CASE(6) NCC_CASE(7) NCC_CASE(8)
         NCC_CASE(9) NCC_CASE(10) NCC_CASE(11) NCC_CASE(12) NCC_CASE(13) NCC_CASE(14) NCC_CASE(15)
+        default: rc = mis_fail(ctx, MIS_ERR_ARG, "dense NCC: unsupported window %d", window);
     }
 #undef NCC_CASE
-    return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: unsupported window %d", window);
+    mis_prof_mark(ctx);
+    return rc;
 }
 
 extern "C" {

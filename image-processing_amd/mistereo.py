@@ -46,7 +46,7 @@ EXPORTS = [
     "mis_xcorr_tiles", "mis_xcorr_tiles_device", "mis_xcorr_tile_surfaces",
     "mis_fft2d_forward", "mis_xcorr_surface_u8",
     "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
-    "mis_version",
+    "mis_profile_enable", "mis_profile_read", "mis_version",
 ]
 
 _lib = None
@@ -80,6 +80,8 @@ def load_library():
         lib.mis_xcorr_surface_u8.argtypes = [vp, vp]
         lib.mis_triangulate.argtypes = [vp, vp, vp, vp, i32, vp]
         lib.mis_triangulate_device.argtypes = [vp, vp, vp, vp, i32, vp]
+        lib.mis_profile_enable.argtypes = [vp, i32]
+        lib.mis_profile_read.argtypes = [vp, vp, vp, vp]
         lib.mis_triangulate_disparity_device.argtypes = [vp, vp, vp, vp, vp, f32, vp, vp]
         _lib = lib
     return _lib
@@ -152,6 +154,15 @@ class Context:
     def use_torch_stream(self):
         import torch
         self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def profile(self, on=True):
+        self._check(self._lib.mis_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        """-> (prepass_ms, main_kernel_ms, calls) summed since the last read."""
+        a, b, n = C.c_double(0), C.c_double(0), C.c_int(0)
+        self._check(self._lib.mis_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     def synchronize(self):
         self._check(self._lib.mis_synchronize(self._h))
