@@ -60,7 +60,7 @@ __device__ __forceinline__ float xyz2(const float* ang1, const float* t1p, const
     float w2x = z2 * ang2[0] + t2p[0];
     float w2y = z2 * ang2[1] + t2p[1];
     float dx = w1x - w2x, dy = w1y - w2y;
-    float err = __fsqrt_rn(dx * dx + dy * dy);
+    float err = sqrtf(dx * dx + dy * dy);   // correctly rounded (the __fsqrt_rn intrinsic is not on gfx950)
     X = w1x; Y = w1y; Z = w1z;
     return err;
 }

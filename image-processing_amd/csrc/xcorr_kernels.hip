@@ -1,9 +1,708 @@
+// Batched FFT tile cross-correlation with difference-of-Gaussian peak pick, gfx950.
+//
+// Replaces findOffset + runFFT (image3.cpp:318-335, 346-517), CalcFFT of image-cross-cor.cpp
+// (104-176) and CalcFFT of image-fft.cpp (45-105).  Stages per tile of w x h pixels (N = w*h):
+//   1 load both tiles (zero outside the bounding box), forward row FFTs              xc_rows_fwd
+//   2 forward column FFTs, spectrum product A*conj(B), inverse column FFT, fused      xc_cols
+//   3 inverse row FFT, |c|, tile min / max                                           xc_rows_inv_abs
+//   4 min-max normalisation to [0,1] and the row pass of the 151-tap Gaussian         xc_norm_rowblur
+//   5 column pass, difference of Gaussians, first maximum                             xc_colblur_argmax
+//   6 wrap the peak position to a signed offset                                       xc_finish
+// Every 1-D transform lives in LDS.  Forward transforms are decimation-in-frequency (natural
+// order in, bit-reversed out), inverse ones decimation-in-time (bit-reversed in, natural out),
+// so the spectrum stays in bit-reversed order in both dimensions between stages 1 and 3 and no
+// reordering pass exists: the pointwise product does not care about the order.
 #include "mis_common.h"
-void mis_xcorr_release(mis_ctx*) {}
-extern "C" {
-int mis_xcorr_tiles(mis_ctx* ctx, const mis_rect*, const mis_rect*, int, int, int, mis_offset*) { return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "not built yet"); }
-int mis_xcorr_tiles_device(mis_ctx* ctx, const mis_rect*, const mis_rect*, int, int, int, mis_offset*) { return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "not built yet"); }
-int mis_xcorr_tile_surfaces(mis_ctx* ctx, mis_rect, mis_rect, int, int, float*, float*) { return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "not built yet"); }
-int mis_fft2d_forward(mis_ctx* ctx, const void*, int, int, int, int, float*) { return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "not built yet"); }
-int mis_xcorr_surface_u8(mis_ctx* ctx, uint8_t*) { return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "not built yet"); }
+
+#include <math.h>
+#include <string.h>
+#include <map>
+#include <vector>
+
+#define XC_GAUSS_K 151          // cv::Size(151,151) at image3.cpp:481
+#define XC_GAUSS_R 75
+#define XC_GAUSS_SIGMA 99.0
+
+struct XcorrWs {
+    std::map<int, float2*> twiddle;     // per FFT length n: n/2 values exp(-2 pi i k / n)
+    float* gauss = nullptr;             // 151 taps
+    void* buf = nullptr; size_t buf_bytes = 0;      // spectra / surfaces of one batch of tiles
+    void* meta = nullptr; size_t meta_bytes = 0;    // per-tile min/max, argmax keys, rects
+};
+
+void mis_xcorr_release(mis_ctx* ctx)
+{
+    XcorrWs* w = ctx->xc;
+    if (!w) return;
+    for (auto& kv : w->twiddle) (void)hipFree(kv.second);
+    if (w->gauss) (void)hipFree(w->gauss);
+    if (w->buf) (void)hipFree(w->buf);
+    if (w->meta) (void)hipFree(w->meta);
+    delete w;
+    ctx->xc = nullptr;
 }
+
+static int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+static int get_twiddle(mis_ctx* ctx, int n, const float2** out)
+{
+    XcorrWs* w = ctx->xc;
+    auto it = w->twiddle.find(n);
+    if (it != w->twiddle.end()) { *out = it->second; return MIS_OK; }
+    std::vector<float2> h((size_t)(n / 2 > 0 ? n / 2 : 1));
+    for (int k = 0; k < n / 2; k++) {
+        double a = -2.0 * M_PI * (double)k / (double)n;
+        h[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    float2* d = nullptr;
+    MIS_HIP(ctx, hipMalloc((void**)&d, h.size() * sizeof(float2)));
+    MIS_HIP(ctx, hipMemcpyAsync(d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    w->twiddle[n] = d;
+    *out = d;
+    return MIS_OK;
+}
+
+// OpenCV 2.4 getGaussianKernel(151, 99, CV_32F): taps exp(-x^2/(2 sigma^2)) evaluated in double,
+// stored as float, normalised by the double sum of the stored floats
+static int ensure_ws(mis_ctx* ctx)
+{
+    if (!ctx->xc) ctx->xc = new XcorrWs();
+    XcorrWs* w = ctx->xc;
+    if (!w->gauss) {
+        float k[XC_GAUSS_K];
+        double scale2x = -0.5 / (XC_GAUSS_SIGMA * XC_GAUSS_SIGMA), sum = 0;
+        for (int i = 0; i < XC_GAUSS_K; i++) {
+            double x = i - (XC_GAUSS_K - 1) * 0.5;
+            k[i] = (float)exp(scale2x * x * x);
+            sum += k[i];
+        }
+        sum = 1. / sum;
+        for (int i = 0; i < XC_GAUSS_K; i++) k[i] = (float)(k[i] * sum);
+        MIS_HIP(ctx, hipMalloc((void**)&w->gauss, sizeof k));
+        MIS_HIP(ctx, hipMemcpyAsync(w->gauss, k, sizeof k, hipMemcpyHostToDevice, ctx->stream));
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// In-LDS radix-2 transforms on `cnt` independent sequences of length n = 2^logn laid out back to
+// back (sequence s occupies x[s*n .. s*n+n)).  All threads of the workgroup take part; the caller
+// has synchronised before the call, and the routines end with a barrier.
+// tw: n/2 values exp(-2 pi i k / n).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// forward (sign -1), decimation in frequency: natural order in, bit-reversed order out
+__device__ void fft_dif_fwd(float2* x, int logn, int cnt, const float2* __restrict__ tw)
+{
+    const int n = 1 << logn;
+    const int total = cnt << (logn - 1);          // butterflies per pass
+    for (int lh = logn - 1; lh >= 0; lh--) {      // half = 2^lh
+        const int half = 1 << lh;
+        for (int b = threadIdx.x; b < total; b += blockDim.x) {
+            const int s = b >> (logn - 1);
+            const int j = b & ((n >> 1) - 1);
+            const int k = j & (half - 1);
+            const int i0 = s * n + ((j >> lh) << (lh + 1)) + k;
+            const float2 a = x[i0], c = x[i0 + half];
+            const float2 w = tw[k << (logn - 1 - lh)];
+            x[i0] = make_float2(a.x + c.x, a.y + c.y);
+            x[i0 + half] = cmul(make_float2(a.x - c.x, a.y - c.y), w);
+        }
+        __syncthreads();
+    }
+}
+
+// backward (sign +1), decimation in time: bit-reversed order in, natural order out, unnormalised
+__device__ void fft_dit_inv(float2* x, int logn, int cnt, const float2* __restrict__ tw)
+{
+    const int n = 1 << logn;
+    const int total = cnt << (logn - 1);
+    for (int lh = 0; lh < logn; lh++) {
+        const int half = 1 << lh;
+        for (int b = threadIdx.x; b < total; b += blockDim.x) {
+            const int s = b >> (logn - 1);
+            const int j = b & ((n >> 1) - 1);
+            const int k = j & (half - 1);
+            const int i0 = s * n + ((j >> lh) << (lh + 1)) + k;
+            float2 w = tw[k << (logn - 1 - lh)];
+            w.y = -w.y;
+            const float2 a = x[i0];
+            const float2 t = cmul(x[i0 + half], w);
+            x[i0] = make_float2(a.x + t.x, a.y + t.y);
+            x[i0 + half] = make_float2(a.x - t.x, a.y - t.y);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int bitrev(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
+
+// ---------------------------------------------------------------------------------------------
+struct XcImage { const void* img[2]; int dtype, iw, ih; size_t stride; };
+
+__device__ __forceinline__ float load_px(const void* img, int dtype, size_t stride, int x, int y)
+{
+    const unsigned char* row = (const unsigned char*)img + (size_t)y * stride;
+    if (dtype == MIS_U8) return (float)row[x];
+    if (dtype == MIS_U16) return (float)((const uint16_t*)row)[x];
+    return ((const float*)row)[x];
+}
+
+// stage 1: grid (rows/RB, 2 images, tiles).  RB rows of one tile per workgroup.
+// spec layout: [tile][img][h][w] float2
+__global__ __launch_bounds__(256) void xc_rows_fwd(XcImage im, const mis_rect* __restrict__ r1,
+                                                   const mis_rect* __restrict__ r2, int tile0,
+                                                   int w, int h, int logw, int RB,
+                                                   const float2* __restrict__ tw, float2* __restrict__ spec)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* x = (float2*)smem_raw;
+    const int t = blockIdx.z, side = blockIdx.y, row0 = blockIdx.x * RB;
+    const mis_rect bb = side ? r2[tile0 + t] : r1[tile0 + t];
+    const void* img = im.img[side];
+    for (int i = threadIdx.x; i < RB * w; i += blockDim.x) {
+        const int ry = row0 + i / w, rx = i % w;
+        float v = 0.f;
+        // image3.cpp:322-328: the buffer is zeroed, then the bbox region is read into it
+        if (rx < bb.width && ry < bb.height) {
+            const int sx = bb.minx + rx, sy = bb.miny + ry;
+            if (sx >= 0 && sx < im.iw && sy >= 0 && sy < im.ih) v = load_px(img, im.dtype, im.stride, sx, sy);
+        }
+        x[i] = make_float2(v, 0.f);
+    }
+    __syncthreads();
+    fft_dif_fwd(x, logw, RB, tw);
+    float2* out = spec + ((size_t)(t * 2 + side) * h + row0) * w;
+    for (int i = threadIdx.x; i < RB * w; i += blockDim.x) out[i] = x[i];
+}
+
+// stage 2: grid (w/CB, tiles).  CB adjacent columns of both spectra of one tile per workgroup.
+// LDS: A[CB][h], B[CB][h] (column-major so that every column is one contiguous sequence).
+__global__ __launch_bounds__(512) void xc_cols(int w, int h, int logh, int CB, float scale,
+                                               const float2* __restrict__ tw, float2* __restrict__ spec)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* A = (float2*)smem_raw;
+    float2* B = A + (size_t)CB * h;
+    const int t = blockIdx.y, c0 = blockIdx.x * CB;
+    float2* sa = spec + (size_t)(t * 2) * h * w;
+    float2* sb = sa + (size_t)h * w;
+    for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
+        const int r = i / CB, c = i % CB;
+        A[c * h + r] = sa[(size_t)r * w + c0 + c];
+        B[c * h + r] = sb[(size_t)r * w + c0 + c];
+    }
+    __syncthreads();
+    fft_dif_fwd(A, logh, 2 * CB, tw);        // A and B are adjacent: 2*CB sequences
+    // runFFT divides each spectrum by sqrt(N) (image3.cpp:331-334); product image3.cpp:392-394
+    for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
+        float2 a = A[i], b = B[i];
+        a.x *= scale; a.y *= scale; b.x *= scale; b.y *= scale;
+        A[i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    }
+    __syncthreads();
+    fft_dit_inv(A, logh, CB, tw);
+    for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
+        const int r = i / CB, c = i % CB;
+        sa[(size_t)r * w + c0 + c] = A[c * h + r];
+    }
+}
+
+__device__ __forceinline__ float wave_min_f(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// stage 3: grid (rows/RB, tiles).  Inverse row transform, divide by sqrt(N) (image3.cpp:401-405),
+// magnitude, tile minimum and maximum (image3.cpp:402-411).  minmax[tile] = {min bits, max bits}
+// of non-negative floats, whose unsigned bit patterns order like the values.
+__global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, int RB, float scale,
+                                                       const float2* __restrict__ tw,
+                                                       const float2* __restrict__ spec,
+                                                       float* __restrict__ surf, unsigned* __restrict__ minmax)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* x = (float2*)smem_raw;
+    const int t = blockIdx.y, row0 = blockIdx.x * RB;
+    const float2* in = spec + ((size_t)(t * 2) * h + row0) * w;
+    for (int i = threadIdx.x; i < RB * w; i += blockDim.x) x[i] = in[i];
+    __syncthreads();
+    fft_dit_inv(x, logw, RB, tw);
+    float* out = surf + ((size_t)t * h + row0) * w;
+    float lo = INFINITY, hi = 0.f;
+    for (int i = threadIdx.x; i < RB * w; i += blockDim.x) {
+        const float2 v = x[i];
+        // cabs() of the complex float promoted to double (image3.cpp:407-410)
+        const float m = (float)hypot((double)(v.x * scale), (double)(v.y * scale));
+        out[i] = m;
+        lo = fminf(lo, m); hi = fmaxf(hi, m);
+    }
+    lo = wave_min_f(lo); hi = wave_max_f(hi);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&minmax[2 * t], __float_as_uint(lo));
+        atomicMax(&minmax[2 * t + 1], __float_as_uint(hi));
+    }
+}
+
+// OpenCV borderInterpolate(p, len, BORDER_REFLECT_101)
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+// stage 4: grid (h, tiles): one row per workgroup.  out = (|c| - min) / (max - min)
+// (image3.cpp:414-416, evaluated in double and narrowed), columns >= 2*(w/2) and rows >= 2*(h/2)
+// zeroed for the blur input (image3.cpp:471-478); row pass of the Gaussian, taps accumulated left
+// to right with separate multiply and add.
+__global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsigned* __restrict__ minmax,
+                                                       const float* __restrict__ gauss,
+                                                       float* __restrict__ surf, float* __restrict__ tmp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* g = (float*)smem_raw;                    // 151 taps (152 slots)
+    float* nrow = g + 152;                          // w normalised samples
+    float* prow = nrow + w;                         // w + 150 reflected samples
+    const int t = blockIdx.y, y = blockIdx.x;
+    const float mn = __uint_as_float(minmax[2 * t]), mx = __uint_as_float(minmax[2 * t + 1]);
+    const float range = mx - mn;
+    float* srow = surf + ((size_t)t * h + y) * w;
+    const int w2 = (w / 2) * 2, h2 = (h / 2) * 2;
+    for (int i = threadIdx.x; i < XC_GAUSS_K; i += blockDim.x) g[i] = gauss[i];
+    for (int x = threadIdx.x; x < w; x += blockDim.x) {
+        const float m = srow[x];
+        const float o = (float)(((double)m - (double)mn) / (double)range);
+        srow[x] = o;                                 // the normalised surface, kept for stage 5
+        nrow[x] = o;
+    }
+    __syncthreads();
+    const int kw = (w == 1) ? 1 : XC_GAUSS_K, rx = kw / 2;
+    for (int i = threadIdx.x; i < w + kw - 1; i += blockDim.x) {
+        const int sx = reflect101(i - rx, w);
+        prow[i] = (sx < w2 && y < h2) ? nrow[sx] : 0.f;
+    }
+    __syncthreads();
+    float* trow = tmp + ((size_t)t * h + y) * w;
+    for (int x = threadIdx.x; x < w; x += blockDim.x) {
+        float acc = 0.f;
+        if (kw == 1) acc = prow[x];
+        else
+            for (int k = 0; k < XC_GAUSS_K; k++) acc = __fadd_rn(acc, __fmul_rn(prow[x + k], g[k]));
+        trow[x] = acc;
+    }
+}
+
+__device__ __forceinline__ unsigned long long argmax_key(float v, unsigned idx)
+{
+    unsigned b = __float_as_uint(v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // order-preserving map to unsigned
+    return ((unsigned long long)b << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+// stage 5: grid (w/64, h/RB5, tiles), 256 threads = 64 columns x 4 row groups.  Column pass of
+// the Gaussian (centre tap first, then symmetric pairs outward), DoG = out - blur
+// (image3.cpp:483), first strict maximum in row-major order above the initial -1
+// (image3.cpp:486-501) as a 64-bit key: ordered value bits, then inverted linear index.
+#define XC_RB5 32
+__global__ __launch_bounds__(256) void xc_colblur_argmax(int w, int h, const float* __restrict__ gauss,
+                                                         const float* __restrict__ surf,
+                                                         const float* __restrict__ tmp,
+                                                         float* __restrict__ dog_out,
+                                                         unsigned long long* __restrict__ keys)
+{
+    __shared__ float col[(XC_RB5 + 2 * XC_GAUSS_R) * 64];
+    __shared__ float g[XC_GAUSS_K];
+    const int t = blockIdx.z, x0 = blockIdx.x * 64, y0 = blockIdx.y * XC_RB5;
+    const int kh = (h == 1) ? 1 : XC_GAUSS_K, ry = kh / 2;
+    const int w2 = (w / 2) * 2, h2 = (h / 2) * 2;
+    const float* tt = tmp + (size_t)t * h * w;
+    for (int i = threadIdx.x; i < XC_GAUSS_K; i += blockDim.x) g[i] = gauss[i];
+    const int nrows = XC_RB5 + 2 * ry;
+    for (int i = threadIdx.x; i < nrows * 64; i += blockDim.x) {
+        const int r = i >> 6, c = i & 63;
+        const int sy = reflect101(y0 - ry + r, h);
+        col[i] = (x0 + c < w) ? tt[(size_t)sy * w + x0 + c] : 0.f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int x = x0 + c;
+    unsigned long long best = 0;
+    for (int j = rg; j < XC_RB5; j += 4) {
+        const int y = y0 + j;
+        if (x >= w || y >= h) continue;
+        float acc;
+        if (kh == 1) acc = col[(j + ry) * 64 + c];
+        else {
+            acc = __fmul_rn(g[XC_GAUSS_R], col[(j + ry) * 64 + c]);
+            for (int k = 1; k <= XC_GAUSS_R; k++) {
+                const float pair = __fadd_rn(col[(j + ry + k) * 64 + c], col[(j + ry - k) * 64 + c]);
+                acc = __fadd_rn(acc, __fmul_rn(g[XC_GAUSS_R + k], pair));
+            }
+        }
+        const size_t o = (size_t)t * h * w + (size_t)y * w + x;
+        const float imout = (x < w2 && y < h2) ? surf[o] : 0.f;
+        const float dog = __fsub_rn(imout, acc);
+        if (dog_out) dog_out[o] = dog;
+        if (x < w2 && y < h2 && dog > -1.0f) {
+            const unsigned long long k = argmax_key(dog, (unsigned)(y * w + x));
+            best = k > best ? k : best;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long other = __shfl_xor(best, o);
+        best = other > best ? other : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(&keys[t], best);
+}
+
+// stage 6: one thread per tile (image3.cpp:507-516)
+__global__ void xc_finish(int n, int w, int h, const unsigned long long* __restrict__ keys,
+                          const unsigned* __restrict__ minmax, const float* __restrict__ surf,
+                          mis_offset* __restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    mis_offset r;
+    const unsigned long long k = keys[t];
+    const bool degenerate = minmax[2 * t] == minmax[2 * t + 1];       // max == min: 0/0 surface
+    if (k == 0 || degenerate) {
+        r.dx = 0; r.dy = 0; r.peak = -1.f; r.dog_peak = -1.f;          // nothing beat the initial -1
+    } else {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu);
+        unsigned b = (unsigned)(k >> 32);
+        b = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b;
+        int col = (int)(idx % (unsigned)w), row = (int)(idx / (unsigned)w);
+        r.peak = surf[(size_t)t * h * w + idx];
+        r.dog_peak = __uint_as_float(b);
+        if (col > w / 2) col -= w;
+        if (row > h / 2) row -= h;
+        r.dx = col; r.dy = row;
+    }
+    out[t] = r;
+}
+
+__global__ void xc_init_meta(int n, unsigned* minmax, unsigned long long* keys)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    minmax[2 * t] = 0x7F800000u;   // +inf
+    minmax[2 * t + 1] = 0u;
+    keys[t] = 0ull;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+struct XcPlan { int w, h, logw, logh, RBw, CB; };
+
+static int make_plan(mis_ctx* ctx, int w, int h, XcPlan* p)
+{
+    if (!is_pow2(w) || !is_pow2(h) || w < 16 || h < 16 || w > 8192 || h > 8192)
+        return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "tile size %d x %d: both sides must be powers of two in 16..8192", w, h);
+    p->w = w; p->h = h; p->logw = ilog2(w); p->logh = ilog2(h);
+    p->RBw = w >= 2048 ? 1 : 2048 / w;          // rows per workgroup: 2048 complex values in LDS
+    if (p->RBw > h) p->RBw = h;
+    p->CB = h >= 4096 ? 1 : 4096 / h;           // columns per workgroup: 2 x 4096 complex values
+    if (p->CB > 16) p->CB = 16;
+    if (p->CB > w) p->CB = w;
+    return MIS_OK;
+}
+
+// correlates tiles [tile0, tile0+nt) of the rect lists (device pointers); results to d_out[tile0..]
+// peak_stages false: stop after stage 3 (|c| surface and its extrema)
+static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const mis_rect* d_r2,
+                     int tile0, int nt, mis_offset* d_out, float* dog_dbg, bool peak_stages = true)
+{
+    XcorrWs* ws = ctx->xc;
+    const int w = p.w, h = p.h;
+    const size_t N = (size_t)w * h;
+    const float2 *tww = nullptr, *twh = nullptr;
+    int rc = get_twiddle(ctx, w, &tww); if (rc) return rc;
+    rc = get_twiddle(ctx, h, &twh); if (rc) return rc;
+
+    float2* spec = (float2*)ws->buf;                                   // [nt][2][h][w]
+    float* surf = (float*)((char*)ws->buf + (size_t)nt * 2 * N * sizeof(float2));   // [nt][h][w]
+    float* tmp = surf + (size_t)nt * N;                                // [nt][h][w]
+    unsigned* minmax = (unsigned*)ws->meta;
+    unsigned long long* keys = (unsigned long long*)((char*)ws->meta + (((size_t)nt * 8 + 255) & ~(size_t)255));
+    hipStream_t s = ctx->stream;
+    const float scale = (float)(1.0 / sqrt((double)N));
+
+    hipLaunchKernelGGL(xc_init_meta, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax, keys);
+    XcImage im;
+    im.img[0] = ctx->img[0]; im.img[1] = ctx->img[1];
+    im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
+    {
+        const size_t sh = (size_t)p.RBw * w * sizeof(float2);
+        if (sh > 64 * 1024) {
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_rows_inv_abs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        }
+        hipLaunchKernelGGL(xc_rows_fwd, dim3(h / p.RBw, 2, nt), dim3(256), sh, s, im, d_r1, d_r2, tile0,
+                           w, h, p.logw, p.RBw, tww, spec);
+    }
+    {
+        const size_t sh = (size_t)2 * p.CB * h * sizeof(float2);
+        if (sh > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(xc_cols, dim3(w / p.CB, nt), dim3(512), sh, s, w, h, p.logh, p.CB, scale, twh, spec);
+    }
+    {
+        const size_t sh = (size_t)p.RBw * w * sizeof(float2);
+        hipLaunchKernelGGL(xc_rows_inv_abs, dim3(h / p.RBw, nt), dim3(256), sh, s, w, h, p.logw, p.RBw, scale,
+                           tww, spec, surf, minmax);
+    }
+    if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
+    {
+        const size_t sh = (size_t)(152 + 2 * w + XC_GAUSS_K) * sizeof(float);
+        hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, surf, tmp);
+    }
+    hipLaunchKernelGGL(xc_colblur_argmax, dim3((w + 63) / 64, (h + XC_RB5 - 1) / XC_RB5, nt), dim3(256), 0, s,
+                       w, h, ws->gauss, surf, tmp, dog_dbg, keys);
+    hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, surf, d_out + tile0);
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+static size_t bytes_per_tile(const XcPlan& p) { return (size_t)p.w * p.h * (2 * sizeof(float2) + 3 * sizeof(float)); }
+
+static int xcorr_run(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, int n, int tile_w, int tile_h,
+                     mis_offset* d_out, float* dog_dbg, bool peak_stages = true)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "tile correlation: no image pair bound");
+    if (n < 0 || (n > 0 && (!d_r1 || !d_r2 || (!d_out && peak_stages)))) return mis_fail(ctx, MIS_ERR_ARG, "tile correlation: NULL buffer");
+    if (n == 0) return MIS_OK;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_ws(ctx); if (rc) return rc;
+    XcPlan p;
+    rc = make_plan(ctx, tile_w, tile_h, &p); if (rc) return rc;
+    // batches bounded by a 2 GiB workspace (one tile minimum)
+    const size_t per = bytes_per_tile(p);
+    int nb = (int)((2048ull << 20) / per);
+    if (nb < 1) nb = 1;
+    if (nb > n) nb = n;
+    if (nb > 65535) nb = 65535;
+    XcorrWs* ws = ctx->xc;
+    rc = mis_reserve(ctx, &ws->buf, &ws->buf_bytes, per * nb); if (rc) return rc;
+    rc = mis_reserve(ctx, &ws->meta, &ws->meta_bytes, (size_t)nb * 16 + 512); if (rc) return rc;
+    for (int t0 = 0; t0 < n; t0 += nb) {
+        const int nt = (n - t0 < nb) ? n - t0 : nb;
+        rc = run_batch(ctx, p, d_r1, d_r2, t0, nt, d_out, dog_dbg, peak_stages);
+        if (rc) return rc;
+    }
+    return MIS_OK;
+}
+
+// forward transform of a batch of rasters with natural-order output (image-fft.cpp:45-105)
+__global__ __launch_bounds__(256) void xc_fft_rows_only(const void* __restrict__ in, int dtype, int w, int h,
+                                                        int logw, int RB, const float2* __restrict__ tw,
+                                                        float2* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* x = (float2*)smem_raw;
+    const int t = blockIdx.y, row0 = blockIdx.x * RB;
+    const int bpp = dtype == MIS_U8 ? 1 : dtype == MIS_U16 ? 2 : 4;
+    const unsigned char* base = (const unsigned char*)in + (size_t)t * h * w * bpp;
+    for (int i = threadIdx.x; i < RB * w; i += blockDim.x)
+        x[i] = make_float2(load_px(base, dtype, (size_t)w * bpp, i % w, row0 + i / w), 0.f);
+    __syncthreads();
+    fft_dif_fwd(x, logw, RB, tw);
+    float2* o = out + ((size_t)t * h + row0) * w;
+    for (int i = threadIdx.x; i < RB * w; i += blockDim.x) o[i] = x[i];     // columns bit-reversed
+}
+
+__global__ __launch_bounds__(512) void xc_fft_cols_only(int w, int h, int logw, int logh, int CB, double norm,
+                                                        const float2* __restrict__ tw,
+                                                        const float2* __restrict__ in, float2* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* A = (float2*)smem_raw;
+    const int t = blockIdx.y, c0 = blockIdx.x * CB;
+    const float2* src = in + (size_t)t * h * w;
+    float2* dst = out + (size_t)t * h * w;
+    for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
+        const int r = i / CB, c = i % CB;
+        A[c * h + r] = src[(size_t)r * w + c0 + c];
+    }
+    __syncthreads();
+    fft_dif_fwd(A, logh, CB, tw);
+    // undo both bit reversals on the way out; divide by sqrt(N) held in double (image-fft.cpp:84-87)
+    for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
+        const int r = i / CB, c = i % CB;
+        const float2 v = A[c * h + r];
+        const int rr = bitrev(r, logh), cc = bitrev(c0 + c, logw);
+        dst[(size_t)rr * w + cc] = make_float2((float)((double)v.x / norm), (float)((double)v.y / norm));
+    }
+}
+
+// image-cross-cor.cpp:166-170: floor(norm * 255) as a byte, then fft2shift (even sizes: a swap of
+// quadrants, i.e. a circular shift by half the size in both directions)
+__global__ __launch_bounds__(256) void xc_quantise_shift(int w, int h, const unsigned* __restrict__ minmax,
+                                                         const float* __restrict__ surf, uint8_t* __restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const float mn = __uint_as_float(minmax[0]), mx = __uint_as_float(minmax[1]);
+    const double v = floor((((double)surf[(size_t)y * w + x] - (double)mn) / (double)(mx - mn)) * 255.0);
+    const uint8_t b = (mx == mn || !(v >= 0)) ? 0 : (uint8_t)v;
+    const int xs = (x + w / 2) % w, ys = (y + h / 2) % h;
+    out[(size_t)ys * w + xs] = b;
+}
+
+extern "C" {
+
+int mis_xcorr_tiles_device(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, int n,
+                           int tile_w, int tile_h, mis_offset* d_out)
+{
+    return xcorr_run(ctx, d_r1, d_r2, n, tile_w, tile_h, d_out, nullptr);
+}
+
+int mis_xcorr_tiles(mis_ctx* ctx, const mis_rect* r1, const mis_rect* r2, int n,
+                    int tile_w, int tile_h, mis_offset* out)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (n < 0 || (n > 0 && (!r1 || !r2 || !out))) return mis_fail(ctx, MIS_ERR_ARG, "tile correlation: NULL buffer");
+    if (n == 0) return MIS_OK;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    void* d = nullptr;
+    const size_t rb = (size_t)n * sizeof(mis_rect), ob = (size_t)n * sizeof(mis_offset);
+    MIS_HIP(ctx, hipMalloc(&d, 2 * rb + ob));
+    mis_rect* d1 = (mis_rect*)d; mis_rect* d2 = d1 + n; mis_offset* dout = (mis_offset*)(d2 + n);
+    int rc = MIS_OK;
+    hipError_t e = hipMemcpyAsync(d1, r1, rb, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d2, r2, rb, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "tile correlation: upload failed: %s", hipGetErrorString(e));
+    if (!rc) rc = xcorr_run(ctx, d1, d2, n, tile_w, tile_h, dout, nullptr);
+    if (!rc) {
+        e = hipMemcpyAsync(out, dout, ob, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "tile correlation: download failed: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+int mis_xcorr_tile_surfaces(mis_ctx* ctx, mis_rect r1, mis_rect r2, int tile_w, int tile_h,
+                            float* surface, float* dog)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "tile correlation: no image pair bound");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)tile_w * tile_h;
+    void* d = nullptr;
+    MIS_HIP(ctx, hipMalloc(&d, 2 * sizeof(mis_rect) + sizeof(mis_offset) + N * sizeof(float)));
+    mis_rect* d1 = (mis_rect*)d; mis_rect* d2 = d1 + 1; mis_offset* dout = (mis_offset*)(d2 + 1);
+    float* ddog = (float*)(dout + 1);
+    int rc = MIS_OK;
+    hipError_t e = hipMemcpyAsync(d1, &r1, sizeof r1, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d2, &r2, sizeof r2, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e));
+    if (!rc) rc = xcorr_run(ctx, d1, d2, 1, tile_w, tile_h, dout, ddog);
+    if (!rc) {
+        const float* surf = (const float*)((char*)ctx->xc->buf + 2 * N * sizeof(float2));
+        if (surface) e = hipMemcpyAsync(surface, surf, N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && dog) e = hipMemcpyAsync(dog, ddog, N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "download failed: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+int mis_fft2d_forward(mis_ctx* ctx, const void* in, int dtype, int w, int h, int batch, float* out_complex)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    const int bpp = mis_pixel_bytes(dtype);
+    if (!in || !out_complex || !bpp || batch < 1) return mis_fail(ctx, MIS_ERR_ARG, "fft2d_forward: bad arguments");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_ws(ctx); if (rc) return rc;
+    XcPlan p;
+    rc = make_plan(ctx, w, h, &p); if (rc) return rc;
+    const float2 *tww = nullptr, *twh = nullptr;
+    rc = get_twiddle(ctx, w, &tww); if (rc) return rc;
+    rc = get_twiddle(ctx, h, &twh); if (rc) return rc;
+    const size_t N = (size_t)w * h;
+    int CB = 8192 / h; if (CB > 16) CB = 16; if (CB > w) CB = w; if (CB < 1) CB = 1;   // one array of <= 8192 values in LDS
+    // rasters are processed in groups that fit a 2 GiB workspace
+    const size_t per = N * (bpp + 2 * sizeof(float2));
+    int nb = (int)((2048ull << 20) / per); if (nb < 1) nb = 1; if (nb > batch) nb = batch; if (nb > 65535) nb = 65535;
+    XcorrWs* ws = ctx->xc;
+    rc = mis_reserve(ctx, &ws->buf, &ws->buf_bytes, per * nb); if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    for (int b0 = 0; b0 < batch; b0 += nb) {
+        const int nt = batch - b0 < nb ? batch - b0 : nb;
+        float2* t1 = (float2*)ws->buf;
+        float2* t2 = t1 + (size_t)nt * N;
+        void* din = (void*)(t2 + (size_t)nt * N);
+        MIS_HIP(ctx, hipMemcpyAsync(din, (const char*)in + (size_t)b0 * N * bpp, (size_t)nt * N * bpp, hipMemcpyHostToDevice, s));
+        const size_t sh1 = (size_t)p.RBw * w * sizeof(float2);
+        if (sh1 > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_fft_rows_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1));
+        hipLaunchKernelGGL(xc_fft_rows_only, dim3(h / p.RBw, nt), dim3(256), sh1, s, din, dtype, w, h, p.logw, p.RBw, tww, t1);
+        const size_t sh2 = (size_t)CB * h * sizeof(float2);
+        if (sh2 > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_fft_cols_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
+        hipLaunchKernelGGL(xc_fft_cols_only, dim3(w / CB, nt), dim3(512), sh2, s, w, h, p.logw, p.logh, CB,
+                           sqrt((double)N), twh, t1, t2);
+        MIS_HIP(ctx, hipGetLastError());
+        MIS_HIP(ctx, hipMemcpyAsync(out_complex + (size_t)b0 * N * 2, t2, (size_t)nt * N * sizeof(float2), hipMemcpyDeviceToHost, s));
+        MIS_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return MIS_OK;
+}
+
+int mis_xcorr_surface_u8(mis_ctx* ctx, uint8_t* out)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "correlation surface: no image pair bound");
+    if (!out) return mis_fail(ctx, MIS_ERR_ARG, "correlation surface: out is NULL");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    const int w = ctx->width, h = ctx->height;
+    const size_t N = (size_t)w * h;
+    void* d = nullptr;
+    MIS_HIP(ctx, hipMalloc(&d, 2 * sizeof(mis_rect) + sizeof(mis_offset) + N));
+    mis_rect* d1 = (mis_rect*)d; mis_rect* d2 = d1 + 1; mis_offset* dout = (mis_offset*)(d2 + 1);
+    uint8_t* d8 = (uint8_t*)(dout + 1);
+    const mis_rect full = { 0, 0, w, h };
+    int rc = MIS_OK;
+    hipError_t e = hipMemcpyAsync(d1, &full, sizeof full, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d2, &full, sizeof full, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e));
+    if (!rc) rc = xcorr_run(ctx, d1, d2, 1, w, h, nullptr, nullptr, false);   // stages 1-3 only
+    if (!rc) {
+        XcorrWs* ws = ctx->xc;
+        const float* surf = (const float*)((char*)ws->buf + 2 * N * sizeof(float2));
+        hipStream_t s = ctx->stream;
+        hipLaunchKernelGGL(xc_quantise_shift, dim3((w + 255) / 256, h), dim3(256), 0, s, w, h,
+                           (const unsigned*)ws->meta, surf, d8);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out, d8, N, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "correlation surface failed: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

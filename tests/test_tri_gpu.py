@@ -1,0 +1,64 @@
+"""Triangulation parity (calculateXYZ, image3.cpp:148-264): bit-exact float32 against the oracle."""
+import numpy as np
+import pytest
+
+import mistereo
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def cameras():
+    A = [[10000, 0, 4096], [0, 10000, 4096], [0, 0, 1]]
+    R = np.eye(3)
+    # OpenCV convention camera = R world + t: a camera at world position C has t = -R C
+    c1 = (A, R, -R @ np.array([0.0, 0.0, 3000.0]))
+    c2 = (A, R, -R @ np.array([900.0, 0.0, 3000.0]))
+    return c1, c2
+
+
+def rotated_cameras():
+    A = [[9000.5, 0, 4000.25], [0, 9100.75, 4100.5], [0, 0, 1]]
+    def rot(ax, ay, az):
+        cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+        return (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+                @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    R1, R2 = rot(0.01, -0.02, 0.005), rot(-0.015, 0.01, -0.02)
+    return (A, R1, -R1 @ np.array([10.0, -5.0, 2800.0])), (A, R2, -R2 @ np.array([850.0, 20.0, 2900.0]))
+
+
+@pytest.mark.parametrize("cams", [cameras, rotated_cameras])
+def test_points_bit_exact(ctx, cams):
+    c1, c2 = cams()
+    rng = np.random.default_rng(1)
+    n = 4096
+    u1 = rng.integers(0, 8192, n); v1 = rng.integers(0, 8192, n)
+    d = rng.integers(-400, 401, n)
+    pts = np.stack([u1, v1, u1 - d, v1 + rng.integers(-2, 3, n)], axis=1).astype(np.int32)
+    pts[:8, 2] = pts[:8, 0]            # zero disparity: parallel rays, the search does not converge
+    pts[8:16] = 0
+    got = ctx.calculate_xyz(mistereo.make_camera(*c1), mistereo.make_camera(*c2), pts)
+    want = oracle.triangulate(oracle.make_camera(*c1), oracle.make_camera(*c2), pts)
+    # bit-exact, NaN payloads aside (zero-disparity rays never intersect: inf/NaN propagate)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+
+
+def test_known_geometry(ctx):
+    """Ground point (X, Y, 0) seen by two nadir cameras 900 m apart at 3000 m: Z comes back near 0."""
+    c1, c2 = cameras()
+    X, Y = 150.0, -80.0
+    f, cx, cy, Hc = 10000.0, 4096.0, 4096.0, 3000.0
+    # ray = (u-cx)/f, -(v-cy)/f, -1 scaled by the height above ground (image3.cpp:185-194)
+    u1, v1 = cx + f * (X - 0.0) / Hc, cy - f * Y / Hc
+    u2, v2 = cx + f * (X - 900.0) / Hc, cy - f * Y / Hc
+    pts = np.array([[round(u1), round(v1), round(u2), round(v2)]], np.int32)
+    got = ctx.calculate_xyz(mistereo.make_camera(*c1), mistereo.make_camera(*c2), pts)[0]
+    assert abs(got[0] - X) < 1.0 and abs(got[1] - Y) < 1.0 and abs(got[2]) < 2.0
+
+
+def test_empty(ctx):
+    c1, c2 = cameras()
+    out = ctx.calculate_xyz(mistereo.make_camera(*c1), mistereo.make_camera(*c2), np.zeros((0, 4), np.int32))
+    assert out.shape == (0, 3)

@@ -1,0 +1,120 @@
+"""FFT tile correlation parity: libmistereo (HIP, through the C ABI) against the CPU oracle's
+restatement of findOffset (image3.cpp:346-517), image-fft.cpp and image-cross-cor.cpp."""
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(h, w, dx, dy, seed, dtype=np.uint8):
+    """img1 content = img2 content moved by (+dx, +dy): peak expected at (dx, dy)."""
+    big = synth.texture(h + 2 * abs(dy) + 8, w + 2 * abs(dx) + 8, seed, dtype)
+    oy, ox = abs(dy) + 4, abs(dx) + 4
+    img2 = big[oy:oy + h, ox:ox + w]
+    img1 = big[oy - dy:oy - dy + h, ox - dx:ox - dx + w]
+    return np.ascontiguousarray(img1), np.ascontiguousarray(img2)
+
+
+@pytest.mark.parametrize("size,dx,dy", [(64, 5, -3), (128, -20, 11), (256, 40, 33), (32, 3, 2), (16, 1, -1)])
+def test_find_offset_single_tile(ctx, size, dx, dy):
+    img1, img2 = _pair(size, size, dx, dy, 100 + size)
+    ctx.upload_pair(img1, img2)
+    peak, ox, oy = ctx.find_offset((0, 0, size, size), (0, 0, size, size), size, size)
+    ref = oracle.find_offset(img1, img2, (0, 0, size, size), (0, 0, size, size), size, size, precision=0)
+    ref64 = oracle.find_offset(img1, img2, (0, 0, size, size), (0, 0, size, size), size, size, precision=1)
+    assert (ox, oy) == (ref["dx"], ref["dy"]) == (ref64["dx"], ref64["dy"])
+    if size >= 64:
+        assert (ox, oy) == (dx, dy)
+    assert abs(peak - ref64["peak"]) <= 1e-4 * max(abs(ref64["peak"]), 1e-3) + 1e-5
+
+
+def test_surfaces_match_oracle(ctx):
+    size = 128
+    img1, img2 = _pair(size, size, 9, -14, 7)
+    ctx.upload_pair(img1, img2)
+    surf, dog = ctx.tile_surfaces((0, 0, size, size), (0, 0, size, size), size, size)
+    ref = oracle.find_offset(img1, img2, (0, 0, size, size), (0, 0, size, size), size, size, precision=1,
+                             want_surface=True, want_dog=True)
+    assert np.abs(surf - ref["surface"]).max() <= 2e-5
+    assert np.abs(dog - ref["dog"]).max() <= 5e-5
+
+
+def test_batched_tiles_with_padding_and_offsets(ctx):
+    """512-px frame, 128-px tiles on a clamped grid (image3.cpp:764-767), tiles of image 2 displaced,
+    one bbox smaller than the tile (zero padding, image3.cpp:322-328)."""
+    rng = np.random.default_rng(5)
+    img1, img2 = _pair(512, 512, 12, -7, 21)
+    ctx.upload_pair(img1, img2)
+    r1, r2 = [], []
+    for j in range(0, 512, 128):
+        for i in range(0, 512, 128):
+            r1.append((i, j, 128, 128))
+            ox, oy = (int(v) for v in rng.integers(-6, 7, 2))
+            r2.append((min(max(i + ox, 0), 384), min(max(j + oy, 0), 384), 128, 128))
+    r1.append((10, 20, 100, 90)); r2.append((14, 20, 100, 90))       # padded tile
+    r1.append((450, 470, 128, 128)); r2.append((450, 470, 128, 128))  # bbox runs off the raster
+    got = ctx.find_offsets(r1, r2, 128, 128)
+    for k, (a, b) in enumerate(zip(r1, r2)):
+        ref = oracle.find_offset(img1, img2, a, b, 128, 128, precision=1)
+        assert (got["dx"][k], got["dy"][k]) == (ref["dx"], ref["dy"]), "tile %d" % k
+        assert abs(got["peak"][k] - ref["peak"]) <= 1e-4 * max(abs(ref["peak"]), 1e-3) + 1e-5
+
+
+def test_rectangular_tile_and_u16_f32(ctx):
+    for dtype in (np.uint16, np.float32):
+        base1, base2 = _pair(64, 256, -17, 4, 3, np.uint16)
+        img1, img2 = base1.astype(dtype), base2.astype(dtype)
+        ctx.upload_pair(img1, img2)
+        peak, ox, oy = ctx.find_offset((0, 0, 256, 64), (0, 0, 256, 64), 256, 64)
+        ref = oracle.find_offset(img1, img2, (0, 0, 256, 64), (0, 0, 256, 64), 256, 64, precision=1)
+        assert (ox, oy) == (ref["dx"], ref["dy"]) == (-17, 4)
+        assert abs(peak - ref["peak"]) <= 1e-4 * abs(ref["peak"]) + 1e-5
+
+
+def test_degenerate_constant_tile(ctx):
+    """max == min: the reference divides 0 by 0, nothing beats the initial -1 (image3.cpp:415, 466-501)."""
+    img = np.zeros((64, 64), np.uint8)
+    ctx.upload_pair(img, img)
+    peak, ox, oy = ctx.find_offset((0, 0, 64, 64), (0, 0, 64, 64), 64, 64)
+    ref = oracle.find_offset(img, img, (0, 0, 64, 64), (0, 0, 64, 64), 64, 64)
+    assert (peak, ox, oy) == (-1.0, 0, 0) == (ref["peak"], ref["dx"], ref["dy"])
+
+
+def test_fft2d_forward_matches_numpy(ctx):
+    rng = np.random.default_rng(11)
+    imgs = rng.integers(0, 256, (3, 64, 128), dtype=np.uint8)
+    got = ctx.fft2d_forward(imgs)
+    for b in range(3):
+        want = np.fft.fft2(imgs[b].astype(np.float64)) / np.sqrt(64 * 128)
+        err = np.linalg.norm(got[b] - want) / np.linalg.norm(want)
+        assert err <= 1e-5
+        o = oracle.fft2d_forward(imgs[b])
+        assert np.linalg.norm(got[b] - o) / np.linalg.norm(o) <= 1e-5
+
+
+def test_fft2d_forward_512(ctx):
+    img = synth.texture(512, 512, 2).astype(np.float32)
+    got = ctx.fft2d_forward(img)
+    want = np.fft.fft2(img.astype(np.float64)) / 512.0
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-5   # accuracy contract at 512^2
+
+
+def test_xcorr_surface_u8(ctx):
+    img1, img2 = _pair(128, 256, 30, -9, 17)
+    ctx.upload_pair(img1, img2)
+    got = ctx.xcorr_surface_u8().astype(np.int32)
+    want = oracle.xcorr_surface_u8(img1, img2, precision=1).astype(np.int32)
+    d = np.abs(got - want)
+    assert d.max() <= 1 and (d > 0).mean() <= 0.02     # floor() of float vs double surfaces
+    py, px = np.unravel_index(np.argmax(got), got.shape)
+    assert (px - 128, py - 64) == (30, -9)              # fft-shifted: offset relative to the centre
+
+
+def test_large_tile_2048(ctx):
+    img1, img2 = _pair(2048, 2048, -100, 57, 9)
+    ctx.upload_pair(img1, img2)
+    peak, ox, oy = ctx.find_offset((0, 0, 2048, 2048), (0, 0, 2048, 2048), 2048, 2048)
+    assert (ox, oy) == (-100, 57) and peak == pytest.approx(1.0, abs=1e-5)
