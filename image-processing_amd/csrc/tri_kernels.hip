@@ -72,7 +72,8 @@ __device__ __forceinline__ void ray(const TriCam& c, int u, int v, float* ang)
     float a1 = -((float)v - c.cy) / c.fy;
     float a2 = -1.0f;
     for (int i = 0; i < 3; i++) {
-        double s = (double)c.Rp[i * 3] * (double)a0;
+        double s = 0.0;                          // the accumulator starts at +0 (sign of a zero result)
+        s += (double)c.Rp[i * 3] * (double)a0;
         s += (double)c.Rp[i * 3 + 1] * (double)a1;
         s += (double)c.Rp[i * 3 + 2] * (double)a2;
         ang[i] = (float)s;

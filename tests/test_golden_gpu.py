@@ -1,0 +1,52 @@
+"""libmistereo against the committed golden vectors (independent numpy restatement)."""
+import os
+
+import numpy as np
+import pytest
+
+import mistereo
+from golden_util import GOLDEN, load_cases
+from ncc_util import compare_ncc, flat_mask
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", ["ncc_u8_w7", "ncc_u8_w15", "ncc_u8_w21"])
+def test_ncc_golden(ctx, case):
+    c = load_cases("ncc_cases.npz")[case]
+    win, dmin, dmax = int(c["window"]), int(c["dmin"]), int(c["dmax"])
+    ctx.upload_pair(c["left"], c["right"])
+    gpu = ctx.ncc_dense(win, dmin, dmax, want_peak2=True)
+    ora = {k: c[k] for k in ("idisp", "disp", "peak", "peak2")}
+    ora["flat"] = flat_mask(c["volume"], c["idisp"], dmin)
+    compare_ncc(gpu, ora, volume=c["volume"], dmin=dmin, check_peak2=True)
+
+
+@pytest.mark.parametrize("case", ["xc32", "xc64", "xc128", "impulse", "padded"])
+def test_find_offset_golden(ctx, case):
+    c = load_cases("xcorr_cases.npz")[case]
+    size = int(c["size"])
+    b1 = tuple(int(v) for v in c["b1"]) if "b1" in c else (0, 0, size, size)
+    b2 = tuple(int(v) for v in c["b2"]) if "b2" in c else (0, 0, size, size)
+    ctx.upload_pair(c["img1"], c["img2"])
+    peak, dx, dy = ctx.find_offset(b1, b2, size, size)
+    assert (dx, dy) == (int(c["dx"]), int(c["dy"]))
+    assert abs(peak - float(c["peak"])) <= 1e-4 * max(abs(float(c["peak"])), 1e-3) + 1e-5
+    surf, dog = ctx.tile_surfaces(b1, b2, size, size)
+    assert np.abs(surf - c["surface"]).max() <= 3e-5
+    assert np.abs(dog - c["dog"]).max() <= 1e-4
+
+
+def test_fft_golden(ctx):
+    z = np.load(os.path.join(GOLDEN, "fft_case.npz"))
+    got = ctx.fft2d_forward(z["img"])
+    assert np.linalg.norm(got - z["spectrum"]) / np.linalg.norm(z["spectrum"]) <= 1e-5
+
+
+def test_triangulation_golden_bit_exact(ctx):
+    z = np.load(os.path.join(GOLDEN, "tri_cases.npz"))
+    for i in range(2):
+        c1 = mistereo.make_camera(z["A1_%d" % i], z["R1_%d" % i], z["T1_%d" % i])
+        c2 = mistereo.make_camera(z["A2_%d" % i], z["R2_%d" % i], z["T2_%d" % i])
+        got = ctx.calculate_xyz(c1, c2, z["pts"])
+        assert np.array_equal(got.view(np.uint32), z["xyz_%d" % i].view(np.uint32))
