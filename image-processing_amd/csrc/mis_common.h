@@ -29,7 +29,7 @@ struct mis_ctx {
     struct XcorrWs* xc = nullptr;
     // optional per-call device timing of the dense-NCC kernels (mis_profile_*)
     bool profile = false;
-    std::vector<hipEvent_t> prof_events;   // triples: start, main kernel start, main kernel end
+    std::vector<hipEvent_t> prof_events;   // per call: start, tables done, main kernel done, end
     size_t prof_used = 0;                  // events handed out since the last read
 
     // triangulation scratch

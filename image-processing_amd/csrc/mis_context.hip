@@ -57,22 +57,25 @@ int mis_profile_enable(mis_ctx* ctx, int on)
     return MIS_OK;
 }
 
-int mis_profile_read(mis_ctx* ctx, double* prepass_ms, double* main_ms, int* calls)
+int mis_profile_read(mis_ctx* ctx, double* tables_ms, double* main_ms, double* refine_ms, int* calls)
 {
     if (!ctx) return MIS_ERR_ARG;
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double pre = 0, mainv = 0;
+    double sum[3] = { 0, 0, 0 };
     int n = 0;
-    for (size_t i = 0; i + 2 < ctx->prof_used && i + 2 < ctx->prof_events.size(); i += 3) {
-        float a = 0, b = 0;
-        MIS_HIP(ctx, hipEventElapsedTime(&a, ctx->prof_events[i], ctx->prof_events[i + 1]));
-        MIS_HIP(ctx, hipEventElapsedTime(&b, ctx->prof_events[i + 1], ctx->prof_events[i + 2]));
-        pre += a; mainv += b; n++;
+    for (size_t i = 0; i + 3 < ctx->prof_used && i + 3 < ctx->prof_events.size(); i += 4) {
+        for (int k = 0; k < 3; k++) {
+            float ms = 0;
+            MIS_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[i + k], ctx->prof_events[i + k + 1]));
+            sum[k] += ms;
+        }
+        n++;
     }
     ctx->prof_used = 0;
-    if (prepass_ms) *prepass_ms = pre;
-    if (main_ms) *main_ms = mainv;
+    if (tables_ms) *tables_ms = sum[0];
+    if (main_ms) *main_ms = sum[1];
+    if (refine_ms) *refine_ms = sum[2];
     if (calls) *calls = n;
     return MIS_OK;
 }

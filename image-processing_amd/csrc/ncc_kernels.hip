@@ -37,6 +37,9 @@ struct NccWs {
     float* Rir = nullptr;       // 1/sqrt(sum (R-mean)^2), 0 when flat, NaN where the window does not fit
     int32_t* hs1 = nullptr;     // horizontal window sums (scratch)
     int32_t* hs2 = nullptr;
+    uint32_t* VL = nullptr;     // [ceil(H/4)][pitch]: 4 vertically adjacent pixels, (p-128) as int8 each
+    uint32_t* VR = nullptr;
+    int16_t* idisp = nullptr;   // integer argmax when the caller does not ask for it
     size_t cap_px = 0;          // capacity in pixels (pitch*rows) of the arrays above
     int pitch = 0, rows = 0;
     uint64_t pair_serial = 0;   // tables valid for this pair ...
@@ -47,7 +50,7 @@ void mis_ncc_release(mis_ctx* ctx)
 {
     NccWs* w = ctx->ncc;
     if (!w) return;
-    void* bufs[] = { w->Lpack, w->negc, w->negg, w->iL, w->Rpack, w->Rsr, w->Rir, w->hs1, w->hs2 };
+    void* bufs[] = { w->Lpack, w->negc, w->negg, w->iL, w->Rpack, w->Rsr, w->Rir, w->hs1, w->hs2, w->VL, w->VR, w->idisp };
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete w;
     ctx->ncc = nullptr;
@@ -134,6 +137,27 @@ __global__ __launch_bounds__(256) void ncc_stats_kernel(const T* __restrict__ im
     o0[o] = v0;
     o1[o] = v1;
     if (LEFT) o2[o] = v2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pre-pass 3: four vertically adjacent pixels per dword, shifted to int8, for v_dot4_i32_i8.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ncc_vpack_kernel(const T* __restrict__ img, size_t stride_px, int W, int H,
+                                                        int pitch, uint32_t* __restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int q = blockIdx.y;
+    if (x >= pitch) return;
+    uint32_t v = 0;
+    if (x < W) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = 4 * q + k;
+            if (y < H) v |= (uint32_t)(((int)img[(size_t)y * stride_px + x] - 128) & 0xFF) << (8 * k);
+        }
+    }
+    out[(size_t)q * pitch + x] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -413,6 +437,308 @@ __global__ __launch_bounds__(1024) void ncc_main_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path (no second-peak output): integer argmax first, exact scores of the winner and its two
+// neighbours afterwards.
+//
+// Argmax kernel: same lane <-> disparity walk as above, but the per-column reduction over the 64
+// lanes is batched.  Every score is turned into a key (low 6 mantissa bits replaced by 63 - lane,
+// so a float maximum also picks the lowest disparity among scores that agree in their upper 26
+// bits); 64 key registers (one per strip column) go through a transposing max network
+// (v_permlane32_swap / v_permlane16_swap, then DPP row and quad steps with write masks) that ends
+// with ONE register holding the 64 column maxima, about 2 vector instructions per column instead
+// of a dependent 6-step reduction per column.  The chunk wavefronts of a workgroup then merge
+// their keys through LDS.
+// ---------------------------------------------------------------------------------------------
+#define NCC_DPP_MAX(dst, src, mods) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " mods : "+v"(dst) : "v"(src))
+
+__device__ __forceinline__ float vmax_raw(float a, float b)
+{
+    float r;
+    asm volatile("s_nop 1\n\tv_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // NaN operands are ignored
+    return r;
+}
+
+// 16 registers (one per column, lane = candidate) -> 1 register in which every 4-lane bank holds
+// the 4 partial maxima of one column
+__device__ __forceinline__ float ncc_reduce16(float (&K)[16])
+{
+    float M[8], N[4], P[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float a = K[i], b = K[i + 8];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        M[i] = vmax_raw(a, b);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float a = M[i], b = M[i + 4];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        N[i] = vmax_raw(a, b);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float o = N[i];
+        NCC_DPP_MAX(o, N[i], "row_ror:8 row_mask:0xf bank_mask:0xf");
+        NCC_DPP_MAX(o, N[i + 2], "row_ror:8 row_mask:0xf bank_mask:0xc");
+        P[i] = o;
+    }
+    float q = P[0];
+    NCC_DPP_MAX(q, P[0], "row_shl:4 row_mask:0xf bank_mask:0x5");
+    NCC_DPP_MAX(q, P[1], "row_shr:4 row_mask:0xf bank_mask:0xa");
+    return q;
+}
+
+// four such registers -> one register with 64 column maxima: lane l holds column
+// (l >> 2) + 32 * (l & 1) + 16 * ((l >> 1) & 1)
+__device__ __forceinline__ float ncc_reduce_quads(float q0, float q1, float q2, float q3, int lane)
+{
+    float t0 = q0, t1 = q1, t2 = q2, t3 = q3;
+    NCC_DPP_MAX(t0, q0, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    NCC_DPP_MAX(t1, q1, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    NCC_DPP_MAX(t2, q2, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    NCC_DPP_MAX(t3, q3, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    float e0 = (lane & 2) ? t1 : t0;
+    float e1 = (lane & 2) ? t3 : t2;
+    float u0 = e0, u1 = e1;
+    NCC_DPP_MAX(u0, e0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    NCC_DPP_MAX(u1, e1, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    return (lane & 1) ? u1 : u0;
+}
+
+template <int R, int WT>
+__global__ __launch_bounds__(1024) void ncc_argmax_kernel(
+    NccArgs a,
+    const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
+    const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr, const float* __restrict__ gRir,
+    int16_t* __restrict__ oIdisp)
+{
+    static_assert(WT == 64 || WT == 32, "strip width");
+    constexpr int WN = 2 * R + 1;
+    constexpr int NC = WT + 2 * R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int lane = threadIdx.x & 63;
+    const int chunk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nchunk = a.nchunk;
+    const int nthreads = nchunk * 64;
+    const int LEN = NC + nchunk * 64;
+
+    float* sBp = (float*)smem_raw;                 // [2][LEN]
+    float* sSR = sBp + 2 * LEN;                    // [2][LEN]
+    float* sIR = sSR + 2 * LEN;                    // [2][LEN]
+    float* sKey = sIR + 2 * LEN;                   // [2][nchunk][64]
+
+    const int x0 = R + blockIdx.x * WT;
+    const int yb0 = a.row0 + blockIdx.y * a.band_rows;
+    const int yb1 = min(yb0 + a.band_rows, a.row1);
+    if (yb0 >= yb1) return;
+    const int nrows = yb1 - yb0;
+    const int T = 2 * R + nrows;
+
+    const int dtop = a.dmin + nchunk * 64 - 1;
+    const int d = a.dmin + chunk * 64 + lane;
+    const int loff = dtop - d;
+    const int xr0 = x0 - R - dtop;
+    // lanes past dmax get a huge negative FINITE bias: -inf would turn into a signalling-NaN bit
+    // pattern once the lane tag is inserted, and v_max_f32 propagates signalling NaNs
+    const float bias = (d <= a.dmax) ? 0.f : -3.0e38f;
+    const uint32_t tag = 63u - (uint32_t)lane;
+    const int mycol = (lane >> 2) + 32 * (lane & 1) + 16 * ((lane >> 1) & 1);   // column of the reduced register
+
+    float C[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) C[k] = 0.f;
+    const int P = a.pitch;
+
+    {
+        const int ynew = yb0 - R;
+        for (int i = threadIdx.x; i < LEN; i += nthreads) {
+            int xr = xr0 + i;
+            bool in = (xr >= 0 && xr < a.W);
+            uint32_t bp = in ? gRpack[(size_t)ynew * P + xr] : 0u;
+            sBp[i] = __builtin_bit_cast(float, bp);
+        }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < T; t++) {
+        const int buf = t & 1;
+        const int ynew = yb0 - R + t;
+        const bool warm = (t < WN);
+        const bool score = (t >= 2 * R);
+        const int yout = ynew - R;
+
+        uint32_t nbp[3] = { 0u, 0u, 0u };      // LEN <= 3 * nthreads (NC <= 128)
+        float nsr[3] = { 0.f, 0.f, 0.f }, nir[3] = { 0.f, 0.f, 0.f };
+        const bool have_next = (t + 1 < T);
+        const bool next_score = (t + 1 >= 2 * R);
+        if (have_next) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                int i = threadIdx.x + q * nthreads;
+                if (i < LEN) {
+                    int xr = xr0 + i;
+                    bool in = (xr >= 0 && xr < a.W);
+                    nbp[q] = in ? gRpack[(size_t)(ynew + 1) * P + xr] : 0u;
+                    if (next_score) {
+                        nsr[q] = in ? gRsr[(size_t)(yout + 1) * P + xr] : 0.f;
+                        nir[q] = in ? gRir[(size_t)(yout + 1) * P + xr] : __builtin_nanf("");
+                    }
+                }
+            }
+        }
+
+        const float* bp = sBp + buf * LEN + loff;
+        const uint32_t* lrow = gLpack + (size_t)ynew * P + (x0 - R);
+        const uint32_t amask = warm ? 0x0000FFFFu : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            uint32_t av = lrow[k] & amask;
+            half2_t ah = __builtin_bit_cast(half2_t, av);
+            half2_t bh = __builtin_bit_cast(half2_t, bp[k]);
+            C[k] = __builtin_amdgcn_fdot2(ah, bh, C[k], false);
+        }
+
+        if (score) {
+            const float* sr = sSR + buf * LEN + loff + R;
+            const float* ir = sIR + buf * LEN + loff + R;
+            const float* ncrow = gNegc + (size_t)yout * P + x0;
+            const float* ngrow = gNegg + (size_t)yout * P + x0;
+            float S = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2 * R; k++) S += C[k];
+            float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
+#pragma unroll
+            for (int b = 0; b < WT / 16; b++) {
+                float K[16];
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) {
+                    const int j = b * 16 + jj;
+                    S += C[j + 2 * R];
+                    const float srv = sr[j];
+                    float tt = __builtin_fmaf(ncrow[j], srv, S);
+                    float cov = __builtin_fmaf(ngrow[j], srv, tt);
+                    float sc = __builtin_fmaf(cov, ir[j], bias);
+                    S -= C[j];
+                    K[jj] = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, sc) & 0xFFFFFFC0u) | tag);
+                }
+                q[b] = ncc_reduce16(K);
+            }
+            const float red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
+            sKey[(buf * nchunk + chunk) * 64 + lane] = red;
+        }
+
+        if (have_next) {
+            const int nb = buf ^ 1;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                int i = threadIdx.x + q * nthreads;
+                if (i < LEN) {
+                    sBp[nb * LEN + i] = __builtin_bit_cast(float, nbp[q]);
+                    if (next_score) { sSR[nb * LEN + i] = nsr[q]; sIR[nb * LEN + i] = nir[q]; }
+                }
+            }
+        }
+        __syncthreads();
+
+        // one wavefront merges the chunks: lowest chunk wins among equal (truncated) scores
+        if (score && chunk == (t % nchunk)) {
+            const int x = x0 + mycol;
+            if (mycol < WT && x < a.W - R) {
+                const float* keys = sKey + (size_t)(buf * nchunk) * 64 + lane;
+                float best = -1.0e30f;                 // below any score, above the bias of masked lanes
+                int dbest = MIS_INVALID_DISP;
+                for (int c = 0; c < nchunk; c++) {
+                    const uint32_t kb = __builtin_bit_cast(uint32_t, keys[c * 64]);
+                    const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
+                    if (v > best) { best = v; dbest = a.dmin + c * 64 + 63 - (int)(kb & 63u); }
+                }
+                oIdisp[(size_t)yout * a.out_pitch + x] = (int16_t)dbest;
+            }
+        }
+    }
+}
+
+// Refinement: exact window correlation of the winner and its two neighbours from vertically packed
+// int8 pixels (v_dot4_i32_i8: four rows per instruction), then the same float expression as the
+// argmax kernel, the parabola vertex and the outputs.  One thread per pixel, 256 pixels of one row
+// per workgroup.
+template <int R>
+__global__ __launch_bounds__(256) void ncc_refine_kernel(
+    NccArgs a, const uint32_t* __restrict__ VL, const uint32_t* __restrict__ VR,
+    const float* __restrict__ gNegc, const float* __restrict__ gNegg, const float* __restrict__ gIL,
+    const float* __restrict__ gRsr, const float* __restrict__ gRir, const int16_t* __restrict__ gIdisp,
+    float* __restrict__ oDisp, float* __restrict__ oPeak)
+{
+    constexpr int NQ = (2 * R + 3) / 4 + 1;      // quads of 4 rows a (2R+1)-row window can touch
+    const int x = R + blockIdx.x * 256 + threadIdx.x;
+    const int y = a.row0 + blockIdx.y;
+    if (x >= a.W - R) return;
+    const int P = a.pitch;
+    const size_t o = (size_t)y * a.out_pitch + x;
+    const int ds = gIdisp[o];
+    if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; return; }
+
+    const int q0 = (y - R) >> 2;
+    uint32_t mask[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; qi++) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int row = 4 * (q0 + qi) + k;
+            if (row >= y - R && row <= y + R) m |= 0xFFu << (8 * k);
+        }
+        mask[qi] = m;
+    }
+    const int nq_rows = (a.H + 3) >> 2;
+    const int u = x - ds;                         // window centre in the right image for the winner
+    int Sm = 0, S0 = 0, Sp = 0;                   // disparities ds-1, ds, ds+1 <-> columns u+1, u, u-1
+    uint32_t ra[NQ], rb[NQ], rc[NQ];              // right columns u+i+1, u+i, u+i-1
+    auto loadR = [&](uint32_t (&dst)[NQ], int col) {
+        col = min(max(col, 0), P - 1);
+#pragma unroll
+        for (int qi = 0; qi < NQ; qi++) {
+            const int q = min(q0 + qi, nq_rows - 1);
+            dst[qi] = VR[(size_t)q * P + col];
+        }
+    };
+    loadR(rb, u - R);
+    loadR(rc, u - R - 1);
+#pragma unroll 1
+    for (int i = -R; i <= R; i++) {
+        loadR(ra, u + i + 1);
+#pragma unroll
+        for (int qi = 0; qi < NQ; qi++) {
+            const int q = min(q0 + qi, nq_rows - 1);
+            const uint32_t l = VL[(size_t)q * P + x + i] & mask[qi];
+            Sm = __builtin_amdgcn_sdot4((int)l, (int)ra[qi], Sm, false);
+            S0 = __builtin_amdgcn_sdot4((int)l, (int)rb[qi], S0, false);
+            Sp = __builtin_amdgcn_sdot4((int)l, (int)rc[qi], Sp, false);
+        }
+#pragma unroll
+        for (int qi = 0; qi < NQ; qi++) { rc[qi] = rb[qi]; rb[qi] = ra[qi]; }
+    }
+
+    const float nc = gNegc[(size_t)y * P + x], ng = gNegg[(size_t)y * P + x], il = gIL[(size_t)y * P + x];
+    auto score = [&](int S, int col, int d) -> float {
+        if (d < a.dmin || d > a.dmax || col < 0 || col >= a.W) return __builtin_nanf("");
+        const float srv = gRsr[(size_t)y * P + col];
+        const float tt = __builtin_fmaf(nc, srv, (float)S);
+        const float cov = __builtin_fmaf(ng, srv, tt);
+        return __builtin_fmaf(cov, gRir[(size_t)y * P + col], 0.f);      // NaN where the window does not fit
+    };
+    const float sm = score(Sm, u + 1, ds - 1), s0 = score(S0, u, ds), sp = score(Sp, u - 1, ds + 1);
+    float delta = 0.f;
+    if (sm == sm && sp == sp) {
+        const float den = 2.f * (sm - 2.f * s0 + sp);
+        if (den != 0.f) delta = fminf(0.5f, fmaxf(-0.5f, (sm - sp) / den));
+    }
+    oDisp[o] = (float)ds + delta;
+    oPeak[o] = s0 * il;
+}
+
 // fills the frame border (pixels whose window does not fit) of rows [row0,row1)
 __global__ __launch_bounds__(256) void ncc_border_kernel(float* disp, float* peak, int16_t* idisp, float* peak2,
                                                          int W, int H, int r, int row0, int row1)
@@ -441,7 +767,8 @@ static int ncc_prepare(mis_ctx* ctx, int window)
     const size_t npx = (size_t)pitch * H;
     if (w->cap_px < npx) {
         void** bufs[] = { (void**)&w->Lpack, (void**)&w->negc, (void**)&w->negg, (void**)&w->iL,
-                          (void**)&w->Rpack, (void**)&w->Rsr, (void**)&w->Rir, (void**)&w->hs1, (void**)&w->hs2 };
+                          (void**)&w->Rpack, (void**)&w->Rsr, (void**)&w->Rir, (void**)&w->hs1, (void**)&w->hs2,
+                          (void**)&w->VL, (void**)&w->VR, (void**)&w->idisp };
         for (void** b : bufs) {
             if (*b) { MIS_HIP(ctx, hipFree(*b)); *b = nullptr; }
         }
@@ -466,6 +793,8 @@ static int ncc_prepare(mis_ctx* ctx, int window)
             else
                 hipLaunchKernelGGL((ncc_stats_kernel<uint8_t, false>), grid, block, 0, s, p, ctx->stride, W, H, r, pitch,
                                    w->hs1, w->hs2, w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
+            hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, dim3((pitch + 255) / 256, (H + 3) / 4), block, 0, s, p, ctx->stride,
+                               W, H, pitch, side == 0 ? w->VL : w->VR);
         } else {
             return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: only 8-bit rasters are supported by this build");
         }
@@ -490,6 +819,30 @@ static int ncc_launch(mis_ctx* ctx, const NccArgs& a, float* d_disp, float* d_pe
         MIS_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, a, w->Lpack, w->negc, w->negg, w->iL,
                        w->Rpack, w->Rsr, w->Rir, d_disp, d_peak, d_idisp, d_peak2);
+    mis_prof_mark(ctx);
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+template <int R, int WT>
+static int ncc_launch_fast(mis_ctx* ctx, const NccArgs& a, float* d_disp, float* d_peak, int16_t* d_idisp)
+{
+    const NccWs* w = ctx->ncc;
+    int16_t* idisp = d_idisp ? d_idisp : w->idisp;
+    {
+        const int nstrips = (a.W - 2 * R + WT - 1) / WT;
+        const int nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
+        const int LEN = WT + 2 * R + a.nchunk * 64;
+        const size_t shmem = (size_t)(6 * LEN + 2 * a.nchunk * 64) * 4;
+        auto kern = ncc_argmax_kernel<R, WT>;
+        if (shmem > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(kern, dim3(nstrips, nbands), dim3(a.nchunk * 64), shmem, ctx->stream, a, w->Lpack, w->negc,
+                           w->negg, w->Rpack, w->Rsr, w->Rir, idisp);
+    }
+    mis_prof_mark(ctx);
+    hipLaunchKernelGGL(ncc_refine_kernel<R>, dim3((a.W - 2 * R + 255) / 256, a.row1 - a.row0), dim3(256), 0, ctx->stream,
+                       a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, idisp, d_disp, d_peak);
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
@@ -513,7 +866,7 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
         dim3 grid((W + 255) / 256, nrows), block(256);
         hipLaunchKernelGGL(ncc_border_kernel, grid, block, 0, ctx->stream, d_disp, d_peak, d_idisp, d_peak2, W, H, r, row0, row0 + nrows);
     }
-    if (W < window || H < window) { mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
+    if (W < window || H < window) { mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
     int rc = ncc_prepare(ctx, window);
     if (rc) return rc;
     mis_prof_mark(ctx);
@@ -525,7 +878,7 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     a.row0 = row0 > r ? row0 : r;
     a.row1 = (row0 + nrows < H - r) ? row0 + nrows : H - r;
     a.out_pitch = W;
-    if (a.row0 >= a.row1) { mis_prof_mark(ctx); return MIS_OK; }
+    if (a.row0 >= a.row1) { mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
     const int nd = dmax - dmin + 1;
     const int total_chunks = (nd + 63) / 64;
     a.band_rows = 128;
@@ -534,7 +887,8 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     // workgroups, which this build does not have
     if (total_chunks > 16) return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: more than 1024 disparities not supported by this build");
     a.nchunk = total_chunks;
-#define NCC_CASE(RR) case RR: rc = ncc_launch<RR, 32>(ctx, a, d_disp, d_peak, d_idisp, d_peak2); break;
+#define NCC_CASE(RR) case RR: rc = d_peak2 ? ncc_launch<RR, 32>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
+                               : ncc_launch_fast<RR, (RR <= 11 ? 64 : 32)>(ctx, a, d_disp, d_peak, d_idisp); break;
     switch (r) {
         NCC_CASE(1) NCC_CASE(2) NCC_CASE(3) NCC_CASE(4) NCC_CASE(5) NCC_CASE(6) NCC_CASE(7) NCC_CASE(8)
         NCC_CASE(9) NCC_CASE(10) NCC_CASE(11) NCC_CASE(12) NCC_CASE(13) NCC_CASE(14) NCC_CASE(15)

@@ -81,7 +81,7 @@ def load_library():
         lib.mis_triangulate.argtypes = [vp, vp, vp, vp, i32, vp]
         lib.mis_triangulate_device.argtypes = [vp, vp, vp, vp, i32, vp]
         lib.mis_profile_enable.argtypes = [vp, i32]
-        lib.mis_profile_read.argtypes = [vp, vp, vp, vp]
+        lib.mis_profile_read.argtypes = [vp, vp, vp, vp, vp]
         lib.mis_triangulate_disparity_device.argtypes = [vp, vp, vp, vp, vp, f32, vp, vp]
         _lib = lib
     return _lib
@@ -159,10 +159,10 @@ class Context:
         self._check(self._lib.mis_profile_enable(self._h, 1 if on else 0))
 
     def profile_read(self):
-        """-> (prepass_ms, main_kernel_ms, calls) summed since the last read."""
-        a, b, n = C.c_double(0), C.c_double(0), C.c_int(0)
-        self._check(self._lib.mis_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)))
-        return a.value, b.value, n.value
+        """-> (tables_ms, main_kernel_ms, refine_ms, calls) summed since the last read."""
+        a, b, c, n = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
+        self._check(self._lib.mis_profile_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return a.value, b.value, c.value, n.value
 
     def synchronize(self):
         self._check(self._lib.mis_synchronize(self._h))

@@ -135,11 +135,11 @@ int mis_triangulate_disparity_device(mis_ctx* ctx, const mis_camera* c1, const m
 
 /* ---- device timing (no counterpart in the reference, which has no timing code) ----------------
  * While enabled, every dense-NCC call records HIP events on the context's stream around its
- * table-building kernels and around its main correlation kernel.  mis_profile_read waits for
- * the stream, returns the summed durations (milliseconds) and the number of calls since the
- * last read, and resets the pool. */
+ * table-building kernels, its main correlation (argmax) kernel and its refinement kernel.
+ * mis_profile_read waits for the stream, returns the summed durations (milliseconds) and the
+ * number of calls since the last read, and resets the pool. */
 int mis_profile_enable(mis_ctx* ctx, int on);
-int mis_profile_read(mis_ctx* ctx, double* prepass_ms, double* main_ms, int* calls);
+int mis_profile_read(mis_ctx* ctx, double* tables_ms, double* main_ms, double* refine_ms, int* calls);
 
 /* library build information: "gfx950 <git describe or date>" */
 const char* mis_version(void);
