@@ -39,7 +39,8 @@ struct NccWs {
     int32_t* hs2 = nullptr;
     uint32_t* VL = nullptr;     // [ceil(H/4)][pitch]: 4 vertically adjacent pixels, (p-128) as int8 each
     uint32_t* VR = nullptr;
-    int16_t* idisp = nullptr;   // integer argmax when the caller does not ask for it
+    float* keys = nullptr;      // [chunks][H][W] best key per pixel and chunk of 64 disparities
+    size_t keys_bytes = 0;
     size_t cap_px = 0;          // capacity in pixels (pitch*rows) of the arrays above
     int pitch = 0, rows = 0;
     uint64_t pair_serial = 0;   // tables valid for this pair ...
@@ -50,7 +51,7 @@ void mis_ncc_release(mis_ctx* ctx)
 {
     NccWs* w = ctx->ncc;
     if (!w) return;
-    void* bufs[] = { w->Lpack, w->negc, w->negg, w->iL, w->Rpack, w->Rsr, w->Rir, w->hs1, w->hs2, w->VL, w->VR, w->idisp };
+    void* bufs[] = { w->Lpack, w->negc, w->negg, w->iL, w->Rpack, w->Rsr, w->Rir, w->hs1, w->hs2, w->VL, w->VR, w->keys };
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete w;
     ctx->ncc = nullptr;
@@ -134,9 +135,15 @@ __global__ __launch_bounds__(256) void ncc_stats_kernel(const T* __restrict__ im
             v1 = inv;
         }
     }
-    o0[o] = v0;
-    o1[o] = v1;
-    if (LEFT) o2[o] = v2;
+    if (LEFT) {
+        // left-image tables are stored shifted left by r columns (entry x-r describes the window
+        // centred at x), so that a strip's first output column x0 = r + 64*strip lands on a 256-byte
+        // boundary for the scalar loads of the correlation kernels
+        if (x >= r) { o0[o - r] = v0; o1[o - r] = v1; o2[o - r] = v2; }
+    } else {
+        o0[o] = v0;
+        o1[o] = v1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -310,8 +317,8 @@ __global__ __launch_bounds__(1024) void ncc_main_kernel(
         if (score) {
             const float* sr = sSR + buf * LEN + loff + R;
             const float* ir = sIR + buf * LEN + loff + R;
-            const float* ncrow = gNegc + (size_t)yout * P + x0;
-            const float* ngrow = gNegg + (size_t)yout * P + x0;
+            const float* ncrow = gNegc + (size_t)yout * P + (x0 - R);
+            const float* ngrow = gNegg + (size_t)yout * P + (x0 - R);
             float rBest = -INFINITY, rIdx = 0.f, rSm = 0.f, rSp = 0.f, rE0 = 0.f, rE63 = 0.f, rSec = -INFINITY;
             float S = 0.f;
 #pragma unroll
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(1024) void ncc_main_kernel(
                         }
                     }
                     const int dbest = a.dmin + bc * 64 + bidx;
-                    const float il = gIL[(size_t)yout * P + x];
+                    const float il = gIL[(size_t)yout * P + (x - R)];
                     oDisp[o] = (float)dbest + delta;
                     oPeak[o] = best * il;
                     if (oIdisp) oIdisp[o] = (int16_t)dbest;
@@ -459,38 +466,52 @@ __device__ __forceinline__ float vmax_raw(float a, float b)
     return r;
 }
 
-// 16 registers (one per column, lane = candidate) -> 1 register in which every 4-lane bank holds
-// the 4 partial maxima of one column
-__device__ __forceinline__ float ncc_reduce16(float (&K)[16])
+// ---- transposing max network, fed one column at a time ----
+__device__ __forceinline__ float ncc_merge32(float a, float b)
 {
-    float M[8], N[4], P[2];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        float a = K[i], b = K[i + 8];
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-        M[i] = vmax_raw(a, b);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float a = M[i], b = M[i + 4];
-        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-        N[i] = vmax_raw(a, b);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        float o = N[i];
-        NCC_DPP_MAX(o, N[i], "row_ror:8 row_mask:0xf bank_mask:0xf");
-        NCC_DPP_MAX(o, N[i + 2], "row_ror:8 row_mask:0xf bank_mask:0xc");
-        P[i] = o;
-    }
-    float q = P[0];
-    NCC_DPP_MAX(q, P[0], "row_shl:4 row_mask:0xf bank_mask:0x5");
-    NCC_DPP_MAX(q, P[1], "row_shr:4 row_mask:0xf bank_mask:0xa");
-    return q;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return vmax_raw(a, b);        // lanes 0-31: column of a, lanes 32-63: column of b
+}
+__device__ __forceinline__ float ncc_merge16(float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return vmax_raw(a, b);        // rows 0,2 from a, rows 1,3 from b
+}
+__device__ __forceinline__ float ncc_merge8(float a, float b)
+{
+    float o = a;
+    NCC_DPP_MAX(o, a, "row_ror:8 row_mask:0xf bank_mask:0xf");
+    NCC_DPP_MAX(o, b, "row_ror:8 row_mask:0xf bank_mask:0xc");
+    return o;                     // lanes 0-7 of every row from a, lanes 8-15 from b
+}
+__device__ __forceinline__ float ncc_merge4(float a, float b)
+{
+    float o = a;
+    NCC_DPP_MAX(o, a, "row_shl:4 row_mask:0xf bank_mask:0x5");
+    NCC_DPP_MAX(o, b, "row_shr:4 row_mask:0xf bank_mask:0xa");
+    return o;                     // banks 0,2 from a, banks 1,3 from b
 }
 
-// four such registers -> one register with 64 column maxima: lane l holds column
-// (l >> 2) + 32 * (l & 1) + 16 * ((l >> 1) & 1)
+// Keys of 16 columns (lane = candidate) -> one register in which every 4-lane bank holds the 4
+// partial maxima of one column.  Columns are pushed one at a time (jj = 0..15, a compile-time
+// constant after unrolling); pairs are merged as soon as both halves exist, so at most five
+// partial registers are alive.
+struct NccTree {
+    float t0, t1, t2, t3, q;
+    __device__ __forceinline__ void push(int jj, float k)
+    {
+        if ((jj & 1) == 0) { t0 = k; return; }
+        const float m1 = ncc_merge32(t0, k);
+        if ((jj & 2) == 0) { t1 = m1; return; }
+        const float m2 = ncc_merge16(t1, m1);
+        if ((jj & 4) == 0) { t2 = m2; return; }
+        const float m3 = ncc_merge8(t2, m2);
+        if ((jj & 8) == 0) { t3 = m3; return; }
+        q = ncc_merge4(t3, m3);
+    }
+};
+
+// four such registers -> one register with 64 column maxima (one per lane)
 __device__ __forceinline__ float ncc_reduce_quads(float q0, float q1, float q2, float q3, int lane)
 {
     float t0 = q0, t1 = q1, t2 = q2, t3 = q3;
@@ -506,29 +527,50 @@ __device__ __forceinline__ float ncc_reduce_quads(float q0, float q1, float q2, 
     return (lane & 1) ? u1 : u0;
 }
 
+// ---- scheduling fences for the hand-pipelined loops below ----
+// The loops load one group of columns ahead of the arithmetic: wait for everything issued so far
+// (LDS and scalar loads share one counter), issue the next group's loads, then compute.  The
+// compiler keeps that order only if it is told to: NCC_WAIT() is a wait it knows about followed by
+// a scheduling barrier; ncc_pin() is an empty asm that reads and writes a value, so work on that
+// value cannot move across it.
+#define NCC_WAIT()                                      \
+    do {                                                \
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */ \
+        __builtin_amdgcn_sched_barrier(0);              \
+    } while (0)
+__device__ __forceinline__ void ncc_pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void ncc_pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
+__device__ __forceinline__ void ncc_pin_s(float& v) { asm volatile("" : "+s"(v)); }
+
+// Argmax kernel: ONE wavefront per workgroup = one chunk of 64 disparities for one strip of WT
+// columns and one band of rows; wavefronts never synchronise with each other.
+// LDS image of the current right-image row, private to the wavefront: 3 arrays (packed pair, S_R,
+// 1/sigma_R), each kept in 4 copies shifted by 0..3 elements so that every lane finds its x-d run
+// 16-byte aligned in one of them (ds_read_b128); LENP % 64 == 16 staggers the copies over the
+// banks.  Output: one key per pixel and chunk (upper 26 bits of the best score, 63 - lane below).
 template <int R, int WT>
-__global__ __launch_bounds__(1024) void ncc_argmax_kernel(
+struct NccWaveCfg {
+    static constexpr int NC = WT + 2 * R;
+    static constexpr int NCP = (NC + 3) & ~3;
+    static constexpr int SEG = NCP + 64 + 4;                       // staged right-image columns
+    static constexpr int LENP = ((SEG + 3 + 47) / 64) * 64 + 16;   // >= SEG + 3, == 16 (mod 64)
+};
+
+template <int R, int WT>
+__global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
     NccArgs a,
     const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
     const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr, const float* __restrict__ gRir,
-    int16_t* __restrict__ oIdisp)
+    float* __restrict__ oKeys)
 {
-    static_assert(WT == 64 || WT == 32, "strip width");
+    static_assert(WT == 64 || WT == 48 || WT == 32, "strip width");
+    using Cfg = NccWaveCfg<R, WT>;
     constexpr int WN = 2 * R + 1;
-    constexpr int NC = WT + 2 * R;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NCP = Cfg::NCP, SEG = Cfg::SEG, LENP = Cfg::LENP;
+    __shared__ __attribute__((aligned(16))) float sArr[12 * LENP];   // [3 arrays][4 copies][LENP]
 
-    const int lane = threadIdx.x & 63;
-    const int chunk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nchunk = a.nchunk;
-    const int nthreads = nchunk * 64;
-    const int LEN = NC + nchunk * 64;
-
-    float* sBp = (float*)smem_raw;                 // [2][LEN]
-    float* sSR = sBp + 2 * LEN;                    // [2][LEN]
-    float* sIR = sSR + 2 * LEN;                    // [2][LEN]
-    float* sKey = sIR + 2 * LEN;                   // [2][nchunk][64]
-
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.z;
     const int x0 = R + blockIdx.x * WT;
     const int yb0 = a.row0 + blockIdx.y * a.band_rows;
     const int yb1 = min(yb0 + a.band_rows, a.row1);
@@ -536,127 +578,175 @@ __global__ __launch_bounds__(1024) void ncc_argmax_kernel(
     const int nrows = yb1 - yb0;
     const int T = 2 * R + nrows;
 
-    const int dtop = a.dmin + nchunk * 64 - 1;
-    const int d = a.dmin + chunk * 64 + lane;
-    const int loff = dtop - d;
-    const int xr0 = x0 - R - dtop;
+    const int dtop = a.dmin + chunk * 64 + 63;      // largest disparity of this chunk
+    const int d = dtop - 63 + lane;
+    const int loff = 63 - lane;                     // LDS element of (column k, this lane) is k + loff
+    const int xr0 = x0 - R - dtop;                  // raster column of LDS element 0
     // lanes past dmax get a huge negative FINITE bias: -inf would turn into a signalling-NaN bit
     // pattern once the lane tag is inserted, and v_max_f32 propagates signalling NaNs
     const float bias = (d <= a.dmax) ? 0.f : -3.0e38f;
     const uint32_t tag = 63u - (uint32_t)lane;
-    const int mycol = (lane >> 2) + 32 * (lane & 1) + 16 * ((lane >> 1) & 1);   // column of the reduced register
 
-    float C[NC];
+    const int cA = loff & 3;
+    const int offB = loff + R, cB = offB & 3;
+
+    // which strip column ends up in this lane of the reduced register: run the network on column ids
+    int mycol;
+    {
+        float qi[4];
 #pragma unroll
-    for (int k = 0; k < NC; k++) C[k] = 0.f;
+        for (int b = 0; b < 4; b++) {
+            NccTree tr;
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) tr.push(jj, (float)(b * 16 + jj));
+            qi[b] = tr.q;
+        }
+        mycol = (int)ncc_reduce_quads(qi[0], qi[1], qi[2], qi[3], lane);
+    }
+
+    float C[NCP];
+#pragma unroll
+    for (int k = 0; k < NCP; k++) C[k] = 0.f;
     const int P = a.pitch;
 
-    {
-        const int ynew = yb0 - R;
-        for (int i = threadIdx.x; i < LEN; i += nthreads) {
-            int xr = xr0 + i;
-            bool in = (xr >= 0 && xr < a.W);
-            uint32_t bp = in ? gRpack[(size_t)ynew * P + xr] : 0u;
-            sBp[i] = __builtin_bit_cast(float, bp);
-        }
-    }
-    __syncthreads();
-
-    for (int t = 0; t < T; t++) {
-        const int buf = t & 1;
-        const int ynew = yb0 - R + t;
-        const bool warm = (t < WN);
-        const bool score = (t >= 2 * R);
-        const int yout = ynew - R;
-
-        uint32_t nbp[3] = { 0u, 0u, 0u };      // LEN <= 3 * nthreads (NC <= 128)
-        float nsr[3] = { 0.f, 0.f, 0.f }, nir[3] = { 0.f, 0.f, 0.f };
-        const bool have_next = (t + 1 < T);
-        const bool next_score = (t + 1 >= 2 * R);
-        if (have_next) {
+    // right-image row -> LDS (this wavefront's columns only); element i <-> raster column xr0 + i
+    uint32_t nbp[3]; float nsr[3], nir[3];
+    auto fetch = [&](int ynew, int yout, bool stats, bool warm) {
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
-                int i = threadIdx.x + q * nthreads;
-                if (i < LEN) {
-                    int xr = xr0 + i;
-                    bool in = (xr >= 0 && xr < a.W);
-                    nbp[q] = in ? gRpack[(size_t)(ynew + 1) * P + xr] : 0u;
-                    if (next_score) {
-                        nsr[q] = in ? gRsr[(size_t)(yout + 1) * P + xr] : 0.f;
-                        nir[q] = in ? gRir[(size_t)(yout + 1) * P + xr] : __builtin_nanf("");
+        for (int q = 0; q < 3; q++) {
+            const int i = lane + 64 * q;
+            const int xr = xr0 + i;
+            const bool in = (xr >= 0 && xr < a.W && i < SEG);
+            uint32_t bp = in ? gRpack[(size_t)ynew * P + xr] : 0u;
+            if (warm) bp &= 0x0000FFFFu;            // warm-up rows: nothing leaves the window yet
+            nbp[q] = bp;
+            nsr[q] = (stats && in) ? gRsr[(size_t)yout * P + xr] : 0.f;
+            nir[q] = stats ? (in ? gRir[(size_t)yout * P + xr] : __builtin_nanf("")) : 0.f;
+        }
+    };
+    auto publish = [&](bool stats) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int i = lane + 64 * q;
+            if (i < SEG) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int pos = i + ((4 - c) & 3);
+                    sArr[(0 * 4 + c) * LENP + pos] = __builtin_bit_cast(float, nbp[q]);
+                    if (stats) {
+                        sArr[(1 * 4 + c) * LENP + pos] = nsr[q];
+                        sArr[(2 * 4 + c) * LENP + pos] = nir[q];
                     }
                 }
             }
         }
+    };
+    fetch(yb0 - R, yb0 - 2 * R, false, true);
+    publish(false);
 
-        const float* bp = sBp + buf * LEN + loff;
-        const uint32_t* lrow = gLpack + (size_t)ynew * P + (x0 - R);
-        const uint32_t amask = warm ? 0x0000FFFFu : 0xFFFFFFFFu;
+    for (int t = 0; t < T; t++) {
+        const int ynew = yb0 - R + t;
+        const bool score = (t >= 2 * R);
+        const int yout = ynew - R;
+        const bool have_next = (t + 1 < T);
+        if (have_next) fetch(ynew + 1, yout + 1, t + 1 >= 2 * R, t + 1 < WN);
+
+        // ---- column sums: add the entering row, drop the leaving row (one v_dot2c each) ----
+        // groups of 16 columns, loads one group ahead of the arithmetic
+        {
+            const float4* bp4 = (const float4*)(sArr + (0 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
+            const uint32_t* lrow = gLpack + (size_t)ynew * P + (x0 - R);
+            constexpr int NGA = (NCP + 15) / 16;
+            float bv[2][16];
+            uint32_t av[2][16];
+            auto loadA = [&](int g, int set) {
 #pragma unroll
-        for (int k = 0; k < NC; k++) {
-            uint32_t av = lrow[k] & amask;
-            half2_t ah = __builtin_bit_cast(half2_t, av);
-            half2_t bh = __builtin_bit_cast(half2_t, bp[k]);
-            C[k] = __builtin_amdgcn_fdot2(ah, bh, C[k], false);
+                for (int v = 0; v < 4; v++) {
+                    if (16 * g + 4 * v < NCP) {
+                        const float4 f = bp4[4 * g + v];
+                        bv[set][4 * v] = f.x; bv[set][4 * v + 1] = f.y; bv[set][4 * v + 2] = f.z; bv[set][4 * v + 3] = f.w;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    if (16 * g + e < NCP) av[set][e] = lrow[16 * g + e];
+            };
+            loadA(0, 0);
+#pragma unroll
+            for (int g = 0; g < NGA; g++) {
+                const int set = g & 1;
+                NCC_WAIT();
+                if (g + 1 < NGA) loadA(g + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int k = 16 * g + e;
+                    if (k < NCP) {
+                        ncc_pin(bv[set][e]);
+                        ncc_pin_s(av[set][e]);
+                        C[k] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, av[set][e]),
+                                                      __builtin_bit_cast(half2_t, bv[set][e]), C[k], false);
+                        ncc_pin(C[k]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         if (score) {
-            const float* sr = sSR + buf * LEN + loff + R;
-            const float* ir = sIR + buf * LEN + loff + R;
-            const float* ncrow = gNegc + (size_t)yout * P + x0;
-            const float* ngrow = gNegg + (size_t)yout * P + x0;
+            const float4* sr4 = (const float4*)(sArr + (1 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
+            const float4* ir4 = (const float4*)(sArr + (2 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
+            const float* ncrow = gNegc + (size_t)yout * P + (x0 - R);
+            const float* ngrow = gNegg + (size_t)yout * P + (x0 - R);
             float S = 0.f;
 #pragma unroll
             for (int k = 0; k < 2 * R; k++) S += C[k];
             float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
+            constexpr int NGB = WT / 8;
+            float sv[2][8], iv[2][8], cv[2][8], gv[2][8];
+            auto loadB = [&](int g, int set) {
 #pragma unroll
-            for (int b = 0; b < WT / 16; b++) {
-                float K[16];
-#pragma unroll
-                for (int jj = 0; jj < 16; jj++) {
-                    const int j = b * 16 + jj;
-                    S += C[j + 2 * R];
-                    const float srv = sr[j];
-                    float tt = __builtin_fmaf(ncrow[j], srv, S);
-                    float cov = __builtin_fmaf(ngrow[j], srv, tt);
-                    float sc = __builtin_fmaf(cov, ir[j], bias);
-                    S -= C[j];
-                    K[jj] = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, sc) & 0xFFFFFFC0u) | tag);
+                for (int v = 0; v < 2; v++) {
+                    const float4 f = sr4[2 * g + v], h = ir4[2 * g + v];
+                    sv[set][4 * v] = f.x; sv[set][4 * v + 1] = f.y; sv[set][4 * v + 2] = f.z; sv[set][4 * v + 3] = f.w;
+                    iv[set][4 * v] = h.x; iv[set][4 * v + 1] = h.y; iv[set][4 * v + 2] = h.z; iv[set][4 * v + 3] = h.w;
                 }
-                q[b] = ncc_reduce16(K);
+#pragma unroll
+                for (int e = 0; e < 8; e++) { cv[set][e] = ncrow[8 * g + e]; gv[set][e] = ngrow[8 * g + e]; }
+            };
+            loadB(0, 0);
+            NccTree tr;
+#pragma unroll
+            for (int g = 0; g < NGB; g++) {
+                const int set = g & 1;
+                NCC_WAIT();
+                if (g + 1 < NGB) loadB(g + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int j = 8 * g + e;
+                    ncc_pin(sv[set][e]); ncc_pin(iv[set][e]);
+                    ncc_pin_s(cv[set][e]); ncc_pin_s(gv[set][e]);
+                    S += C[j + 2 * R];
+                    const float tt = __builtin_fmaf(cv[set][e], sv[set][e], S);     // S - c*S_R, exact
+                    const float cov = __builtin_fmaf(gv[set][e], sv[set][e], tt);   // - (rem/N)*S_R
+                    const float sc = __builtin_fmaf(cov, iv[set][e], bias);
+                    S -= C[j];
+                    tr.push(j & 15, __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, sc) & 0xFFFFFFC0u) | tag));
+                }
+                if ((g & 1) == 1) q[g >> 1] = tr.q;
+                ncc_pin(S);
+                __builtin_amdgcn_sched_barrier(0);
             }
             const float red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
-            sKey[(buf * nchunk + chunk) * 64 + lane] = red;
-        }
-
-        if (have_next) {
-            const int nb = buf ^ 1;
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                int i = threadIdx.x + q * nthreads;
-                if (i < LEN) {
-                    sBp[nb * LEN + i] = __builtin_bit_cast(float, nbp[q]);
-                    if (next_score) { sSR[nb * LEN + i] = nsr[q]; sIR[nb * LEN + i] = nir[q]; }
-                }
-            }
-        }
-        __syncthreads();
-
-        // one wavefront merges the chunks: lowest chunk wins among equal (truncated) scores
-        if (score && chunk == (t % nchunk)) {
             const int x = x0 + mycol;
-            if (mycol < WT && x < a.W - R) {
-                const float* keys = sKey + (size_t)(buf * nchunk) * 64 + lane;
-                float best = -1.0e30f;                 // below any score, above the bias of masked lanes
-                int dbest = MIS_INVALID_DISP;
-                for (int c = 0; c < nchunk; c++) {
-                    const uint32_t kb = __builtin_bit_cast(uint32_t, keys[c * 64]);
-                    const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
-                    if (v > best) { best = v; dbest = a.dmin + c * 64 + 63 - (int)(kb & 63u); }
-                }
-                oIdisp[(size_t)yout * a.out_pitch + x] = (int16_t)dbest;
-            }
+            if (mycol < WT && x < a.W - R)
+                oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red;
         }
+
+        // the LDS image is single-buffered: every read of this row was issued above, LDS executes a
+        // wavefront's operations in order, so the next row may be written now
+        if (have_next) publish(t + 1 >= 2 * R);
     }
 }
 
@@ -668,8 +758,8 @@ template <int R>
 __global__ __launch_bounds__(256) void ncc_refine_kernel(
     NccArgs a, const uint32_t* __restrict__ VL, const uint32_t* __restrict__ VR,
     const float* __restrict__ gNegc, const float* __restrict__ gNegg, const float* __restrict__ gIL,
-    const float* __restrict__ gRsr, const float* __restrict__ gRir, const int16_t* __restrict__ gIdisp,
-    float* __restrict__ oDisp, float* __restrict__ oPeak)
+    const float* __restrict__ gRsr, const float* __restrict__ gRir, const float* __restrict__ gKeys, int nchunk,
+    float* __restrict__ oDisp, float* __restrict__ oPeak, int16_t* __restrict__ oIdisp)
 {
     constexpr int NQ = (2 * R + 3) / 4 + 1;      // quads of 4 rows a (2R+1)-row window can touch
     const int x = R + blockIdx.x * 256 + threadIdx.x;
@@ -677,7 +767,17 @@ __global__ __launch_bounds__(256) void ncc_refine_kernel(
     if (x >= a.W - R) return;
     const int P = a.pitch;
     const size_t o = (size_t)y * a.out_pitch + x;
-    const int ds = gIdisp[o];
+    // merge the chunk keys: lowest chunk wins among equal (truncated) scores
+    int ds = MIS_INVALID_DISP;
+    {
+        float best = -1.0e30f;                     // below any score, above the bias of masked lanes
+        for (int c = 0; c < nchunk; c++) {
+            const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * a.H * a.out_pitch + o]);
+            const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
+            if (v > best) { best = v; ds = a.dmin + c * 64 + 63 - (int)(kb & 63u); }
+        }
+    }
+    if (oIdisp) oIdisp[o] = (int16_t)ds;
     if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; return; }
 
     const int q0 = (y - R) >> 2;
@@ -721,7 +821,7 @@ __global__ __launch_bounds__(256) void ncc_refine_kernel(
         for (int qi = 0; qi < NQ; qi++) { rc[qi] = rb[qi]; rb[qi] = ra[qi]; }
     }
 
-    const float nc = gNegc[(size_t)y * P + x], ng = gNegg[(size_t)y * P + x], il = gIL[(size_t)y * P + x];
+    const float nc = gNegc[(size_t)y * P + (x - R)], ng = gNegg[(size_t)y * P + (x - R)], il = gIL[(size_t)y * P + (x - R)];
     auto score = [&](int S, int col, int d) -> float {
         if (d < a.dmin || d > a.dmax || col < 0 || col >= a.W) return __builtin_nanf("");
         const float srv = gRsr[(size_t)y * P + col];
@@ -768,7 +868,7 @@ static int ncc_prepare(mis_ctx* ctx, int window)
     if (w->cap_px < npx) {
         void** bufs[] = { (void**)&w->Lpack, (void**)&w->negc, (void**)&w->negg, (void**)&w->iL,
                           (void**)&w->Rpack, (void**)&w->Rsr, (void**)&w->Rir, (void**)&w->hs1, (void**)&w->hs2,
-                          (void**)&w->VL, (void**)&w->VR, (void**)&w->idisp };
+                          (void**)&w->VL, (void**)&w->VR };
         for (void** b : bufs) {
             if (*b) { MIS_HIP(ctx, hipFree(*b)); *b = nullptr; }
         }
@@ -825,24 +925,19 @@ static int ncc_launch(mis_ctx* ctx, const NccArgs& a, float* d_disp, float* d_pe
 }
 
 template <int R, int WT>
-static int ncc_launch_fast(mis_ctx* ctx, const NccArgs& a, float* d_disp, float* d_peak, int16_t* d_idisp)
+static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
 {
-    const NccWs* w = ctx->ncc;
-    int16_t* idisp = d_idisp ? d_idisp : w->idisp;
-    {
-        const int nstrips = (a.W - 2 * R + WT - 1) / WT;
-        const int nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
-        const int LEN = WT + 2 * R + a.nchunk * 64;
-        const size_t shmem = (size_t)(6 * LEN + 2 * a.nchunk * 64) * 4;
-        auto kern = ncc_argmax_kernel<R, WT>;
-        if (shmem > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(kern, dim3(nstrips, nbands), dim3(a.nchunk * 64), shmem, ctx->stream, a, w->Lpack, w->negc,
-                           w->negg, w->Rpack, w->Rsr, w->Rir, idisp);
-    }
+    NccWs* w = ctx->ncc;
+    const size_t keys_bytes = (size_t)a.nchunk * a.H * a.W * sizeof(float);
+    int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, keys_bytes);
+    if (rc) return rc;
+    const int nstrips = (a.W - 2 * R + WT - 1) / WT;
+    const int nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
+    hipLaunchKernelGGL((ncc_argmax_kernel<R, WT>), dim3(nstrips, nbands, a.nchunk), dim3(64), 0, ctx->stream,
+                       a, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
     mis_prof_mark(ctx);
     hipLaunchKernelGGL(ncc_refine_kernel<R>, dim3((a.W - 2 * R + 255) / 256, a.row1 - a.row0), dim3(256), 0, ctx->stream,
-                       a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, idisp, d_disp, d_peak);
+                       a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, a.nchunk, d_disp, d_peak, d_idisp);
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
@@ -885,7 +980,8 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
 
     // a workgroup holds at most 16 wavefronts: wider ranges would need a merge across
     // workgroups, which this build does not have
-    if (total_chunks > 16) return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: more than 1024 disparities not supported by this build");
+    if (total_chunks > 16 && d_peak2)
+        return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: the second-peak output supports at most 1024 disparities");
     a.nchunk = total_chunks;
 #define NCC_CASE(RR) case RR: rc = d_peak2 ? ncc_launch<RR, 32>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
                                : ncc_launch_fast<RR, (RR <= 11 ? 64 : 32)>(ctx, a, d_disp, d_peak, d_idisp); break;
