@@ -85,6 +85,9 @@ __global__ __launch_bounds__(256) void ncc_hsum_kernel(const T* __restrict__ img
 // ---------------------------------------------------------------------------------------------
 // Pre-pass 2: vertical sums -> window statistics, and the packed row pairs.
 // ---------------------------------------------------------------------------------------------
+// One thread per column walks down a band of rows, sliding the vertical window over the
+// horizontal sums (two loads in, two loads out per row).
+#define NCC_STATS_BAND 128
 template <typename T, bool LEFT>
 __global__ __launch_bounds__(256) void ncc_stats_kernel(const T* __restrict__ img, size_t stride_px,
                                                         int W, int H, int r, int pitch,
@@ -96,53 +99,64 @@ __global__ __launch_bounds__(256) void ncc_stats_kernel(const T* __restrict__ im
                                                         float* __restrict__ o2)   // LEFT: iL
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
     if (x >= pitch) return;
-    const size_t o = (size_t)y * pitch + x;
+    const int y0 = blockIdx.y * NCC_STATS_BAND;
+    const int y1 = min(y0 + NCC_STATS_BAND, H);
     const int Wn = 2 * r + 1;
-    // packed pair: this row and the row Wn above
-    float a = 0.f, b = 0.f;
-    if (x < W) {
-        a = (float)((int)img[(size_t)y * stride_px + x] - 128);
-        if (y - Wn >= 0) b = (float)((int)img[(size_t)(y - Wn) * stride_px + x] - 128);
-    }
-    half2_t h;
-    h.x = (_Float16)a;
-    h.y = (_Float16)(LEFT ? -b : b);
-    pack[o] = __builtin_bit_cast(uint32_t, h);
-
+    const long long N = (long long)Wn * Wn;
     const bool colok = (x >= r && x < W - r);
-    const bool rowok = (y >= r && y < H - r);
-    float v0 = 0.f, v1 = LEFT ? 0.f : (colok ? 0.f : __builtin_nanf("")), v2 = 0.f;
-    if (colok && rowok) {
-        long long s1 = 0, s2 = 0;
-        for (int j = -r; j <= r; j++) {
-            s1 += hs1[(size_t)(y + j) * pitch + x];   // hs*[..][x]: horizontal window centred at x
-            s2 += hs2[(size_t)(y + j) * pitch + x];
+    long long s1 = 0, s2 = 0;           // window sums for the rows y-r .. y+r
+    bool have = false;
+    for (int y = y0; y < y1; y++) {
+        const size_t o = (size_t)y * pitch + x;
+        // packed pair: this row and the row Wn above
+        float a = 0.f, b = 0.f;
+        if (x < W) {
+            a = (float)((int)img[(size_t)y * stride_px + x] - 128);
+            if (y - Wn >= 0) b = (float)((int)img[(size_t)(y - Wn) * stride_px + x] - 128);
         }
-        const long long N = (long long)Wn * Wn;
-        const long long var = N * s2 - s1 * s1;            // N * sum (p-mean)^2, exact
-        const float inv = var > 0 ? (float)sqrt((double)N / (double)var) : 0.f;
+        half2_t h;
+        h.x = (_Float16)a;
+        h.y = (_Float16)(LEFT ? -b : b);
+        pack[o] = __builtin_bit_cast(uint32_t, h);
+
+        const bool rowok = (y >= r && y < H - r);
+        float v0 = 0.f, v1 = LEFT ? 0.f : (colok ? 0.f : __builtin_nanf("")), v2 = 0.f;
+        if (colok && rowok) {
+            if (!have) {
+                s1 = 0; s2 = 0;
+                for (int j = -r; j <= r; j++) {
+                    s1 += hs1[(size_t)(y + j) * pitch + x];   // hs*[..][x]: horizontal window centred at x
+                    s2 += hs2[(size_t)(y + j) * pitch + x];
+                }
+                have = true;
+            } else {
+                s1 += hs1[(size_t)(y + r) * pitch + x] - hs1[(size_t)(y - r - 1) * pitch + x];
+                s2 += hs2[(size_t)(y + r) * pitch + x] - hs2[(size_t)(y - r - 1) * pitch + x];
+            }
+            const long long var = N * s2 - s1 * s1;            // N * sum (p-mean)^2, exact
+            const float inv = var > 0 ? (float)sqrt((double)N / (double)var) : 0.f;
+            if (LEFT) {
+                long long c = (2 * s1 + N) / (2 * N);          // round(s1/N) for s1 >= 0 ...
+                if (2 * s1 + N < 0) c = -((-(2 * s1 + N) + 2 * N - 1) / (2 * N));   // ... floor for negatives
+                const long long rem = s1 - N * c;
+                v0 = -(float)c;
+                v1 = -(float)((double)rem / (double)N);
+                v2 = inv;
+            } else {
+                v0 = (float)s1;
+                v1 = inv;
+            }
+        }
         if (LEFT) {
-            long long c = (2 * s1 + N) / (2 * N);          // round(s1/N) for s1 >= 0 ...
-            if (2 * s1 + N < 0) c = -((-(2 * s1 + N) + 2 * N - 1) / (2 * N));   // ... floor for negatives
-            const long long rem = s1 - N * c;
-            v0 = -(float)c;
-            v1 = -(float)((double)rem / (double)N);
-            v2 = inv;
+            // left-image tables are stored shifted left by r columns (entry x-r describes the window
+            // centred at x), so that a strip's first output column x0 = r + 64*strip lands on a
+            // 256-byte boundary for the scalar loads of the correlation kernels
+            if (x >= r) { o0[o - r] = v0; o1[o - r] = v1; o2[o - r] = v2; }
         } else {
-            v0 = (float)s1;
-            v1 = inv;
+            o0[o] = v0;
+            o1[o] = v1;
         }
-    }
-    if (LEFT) {
-        // left-image tables are stored shifted left by r columns (entry x-r describes the window
-        // centred at x), so that a strip's first output column x0 = r + 64*strip lands on a 256-byte
-        // boundary for the scalar loads of the correlation kernels
-        if (x >= r) { o0[o - r] = v0; o1[o - r] = v1; o2[o - r] = v2; }
-    } else {
-        o0[o] = v0;
-        o1[o] = v1;
     }
 }
 
@@ -881,6 +895,7 @@ static int ncc_prepare(mis_ctx* ctx, int window)
         return MIS_OK;
     w->pitch = pitch; w->rows = H;
     dim3 grid((pitch + 255) / 256, H), block(256);
+    dim3 sgrid((pitch + 255) / 256, (H + NCC_STATS_BAND - 1) / NCC_STATS_BAND);
     hipStream_t s = ctx->stream;
     for (int side = 0; side < 2; side++) {
         const void* img = ctx->img[side];
@@ -888,10 +903,10 @@ static int ncc_prepare(mis_ctx* ctx, int window)
             const uint8_t* p = (const uint8_t*)img;
             hipLaunchKernelGGL(ncc_hsum_kernel<uint8_t>, grid, block, 0, s, p, ctx->stride, W, H, r, pitch, w->hs1, w->hs2);
             if (side == 0)
-                hipLaunchKernelGGL((ncc_stats_kernel<uint8_t, true>), grid, block, 0, s, p, ctx->stride, W, H, r, pitch,
+                hipLaunchKernelGGL((ncc_stats_kernel<uint8_t, true>), sgrid, block, 0, s, p, ctx->stride, W, H, r, pitch,
                                    w->hs1, w->hs2, w->Lpack, w->negc, w->negg, w->iL);
             else
-                hipLaunchKernelGGL((ncc_stats_kernel<uint8_t, false>), grid, block, 0, s, p, ctx->stride, W, H, r, pitch,
+                hipLaunchKernelGGL((ncc_stats_kernel<uint8_t, false>), sgrid, block, 0, s, p, ctx->stride, W, H, r, pitch,
                                    w->hs1, w->hs2, w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
             hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, dim3((pitch + 255) / 256, (H + 3) / 4), block, 0, s, p, ctx->stride,
                                W, H, pitch, side == 0 ? w->VL : w->VR);
