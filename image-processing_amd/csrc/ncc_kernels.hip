@@ -190,6 +190,7 @@ struct NccArgs {
     int row0, row1;      // output rows [row0,row1), already clipped to [r, H-r)
     int band_rows;       // rows per workgroup
     int out_pitch;       // elements per output row (== W)
+    int nstrips, nbands; // fast path: work decomposition (strips of columns, bands of rows)
 };
 
 #define DPP_QUAD_1032 0xB1
@@ -584,9 +585,22 @@ __global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
     __shared__ __attribute__((aligned(16))) float sArr[12 * LENP];   // [3 arrays][4 copies][LENP]
 
     const int lane = threadIdx.x;
-    const int chunk = blockIdx.z;
-    const int x0 = R + blockIdx.x * WT;
-    const int yb0 = a.row0 + blockIdx.y * a.band_rows;
+    // Workgroups are dealt to the 8 XCDs round-robin (ids b and b+8 share an L2).  Remap the id so
+    // that every XCD works through a contiguous run of work items, ordered chunk-fastest: the
+    // wavefronts resident on one XCD then read the same left-image rows and overlapping
+    // right-image columns (an affinity for speed only, nothing depends on it).
+    int chunk, strip, band;
+    {
+        const int total = a.nstrips * a.nbands * a.nchunk;
+        const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
+        const int q = total >> 3, rem = total & 7;
+        const int wid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+        chunk = wid % a.nchunk;
+        strip = (wid / a.nchunk) % a.nstrips;
+        band = wid / (a.nchunk * a.nstrips);
+    }
+    const int x0 = R + strip * WT;
+    const int yb0 = a.row0 + band * a.band_rows;
     const int yb1 = min(yb0 + a.band_rows, a.row1);
     if (yb0 >= yb1) return;
     const int nrows = yb1 - yb0;
@@ -946,9 +960,9 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     const size_t keys_bytes = (size_t)a.nchunk * a.H * a.W * sizeof(float);
     int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, keys_bytes);
     if (rc) return rc;
-    const int nstrips = (a.W - 2 * R + WT - 1) / WT;
-    const int nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
-    hipLaunchKernelGGL((ncc_argmax_kernel<R, WT>), dim3(nstrips, nbands, a.nchunk), dim3(64), 0, ctx->stream,
+    a.nstrips = (a.W - 2 * R + WT - 1) / WT;
+    a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
+    hipLaunchKernelGGL((ncc_argmax_kernel<R, WT>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
                        a, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
     mis_prof_mark(ctx);
     hipLaunchKernelGGL(ncc_refine_kernel<R>, dim3((a.W - 2 * R + 255) / 256, a.row1 - a.row0), dim3(256), 0, ctx->stream,
@@ -988,6 +1002,7 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     a.row0 = row0 > r ? row0 : r;
     a.row1 = (row0 + nrows < H - r) ? row0 + nrows : H - r;
     a.out_pitch = W;
+    a.nstrips = a.nbands = 0;
     if (a.row0 >= a.row1) { mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
     const int nd = dmax - dmin + 1;
     const int total_chunks = (nd + 63) / 64;
