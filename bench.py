@@ -46,7 +46,8 @@ def load_traffic_note(kernel_name):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel_name)
+            entry = json.load(f).get(kernel_name)
+        return entry.get("bytes") if isinstance(entry, dict) else entry
     except Exception:
         return None
 
