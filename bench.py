@@ -52,6 +52,37 @@ def load_traffic_note(kernel_name):
         return None
 
 
+class GatherPipeline:
+    """Double-buffered gather of per-rank result rasters to rank 0, overlapped with the next step.
+
+    submit(b) starts an asynchronous torch.distributed.gather of buffer b; reuse(b) must be called
+    before buffer b is written again and waits for that gather.  Works with any backend (RCCL on
+    the GPU box, gloo in the CPU tests)."""
+
+    def __init__(self, rank, world, buffers, dst=0):
+        import torch
+        self.rank, self.world, self.dst = rank, world, dst
+        self.buffers = buffers
+        self.pending = [None] * len(buffers)
+        self.gathered = None
+        if rank == dst:
+            self.gathered = [[torch.empty_like(b) for _ in range(world)] for b in buffers]
+
+    def reuse(self, b):
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+
+    def submit(self, b):
+        import torch.distributed as dist
+        self.pending[b] = dist.gather(self.buffers[b], self.gathered[b] if self.rank == self.dst else None,
+                                      dst=self.dst, async_op=True)
+
+    def drain(self):
+        for b in range(len(self.buffers)):
+            self.reuse(b)
+
+
 def main():
     args = parse()
     import numpy as np
@@ -97,21 +128,16 @@ def main():
     disp = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     peak = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     do_gather = world > 1 and args.gather == "on"
-    gathered = None
-    if do_gather and rank == 0:
-        gathered = [[torch.empty((2, H, W), dtype=torch.float32, device=dev) for _ in range(world)] for _ in range(nbuf)]
     packed = [torch.empty((2, H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
+    pipe = GatherPipeline(rank, world, packed) if do_gather else None
 
     ctx = mistereo.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
-    pending = [None] * nbuf
-
     def step(i):
         b = i % nbuf
-        if pending[b] is not None:
-            pending[b].wait()          # the buffer's previous gather has drained
-            pending[b] = None
+        if pipe:
+            pipe.reuse(b)              # the buffer's previous gather has drained
         with torch.cuda.stream(stream):
             # re-binding invalidates the context's per-pair tables: every step redoes all the work
             ctx.bind_pair_torch(left, right)
@@ -123,13 +149,11 @@ def main():
             ev = torch.cuda.Event()
             ev.record(stream)
             torch.cuda.current_stream().wait_event(ev)
-            pending[b] = dist.gather(packed[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+            pipe.submit(b)
 
     def drain():
-        for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        if pipe:
+            pipe.drain()
         stream.synchronize()
         torch.cuda.synchronize()
 

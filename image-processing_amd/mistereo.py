@@ -33,6 +33,12 @@ class Camera(C.Structure):
     _fields_ = [("A", C.c_float * 9), ("R", C.c_float * 9), ("T", C.c_float * 3)]
 
 
+class Leaf(C.Structure):
+    _fields_ = [("bbox1", Rect), ("total_dx", C.c_int32), ("total_dy", C.c_int32),
+                ("u1", C.c_int32), ("v1", C.c_int32), ("u2", C.c_int32), ("v2", C.c_int32),
+                ("peak", C.c_float)]
+
+
 class MisError(RuntimeError):
     def __init__(self, code, msg):
         RuntimeError.__init__(self, "libmistereo error %d: %s" % (code, msg))
@@ -46,6 +52,7 @@ EXPORTS = [
     "mis_xcorr_tiles", "mis_xcorr_tiles_device", "mis_xcorr_tile_surfaces",
     "mis_fft2d_forward", "mis_xcorr_surface_u8",
     "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
+    "mis_disparity_map", "mis_write_xyz", "mis_rasterize_leaves",
     "mis_profile_enable", "mis_profile_read", "mis_version",
 ]
 
@@ -59,6 +66,13 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libmistereo.so is missing (%s): build it with `make -C image-processing_amd`; "
                               "there is no CPU fallback" % LIB_PATH)
+        # PyTorch ships its own libamdhip64 with the same soname as /opt/rocm's.  Whichever is loaded
+        # first serves the whole process, and torch cannot find the GPU when it is not its own: load
+        # torch's first when torch is installed (tests and bench.py share device memory with it).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.mis_last_error.restype = C.c_char_p
         lib.mis_last_error.argtypes = [C.c_void_p]
@@ -80,6 +94,9 @@ def load_library():
         lib.mis_xcorr_surface_u8.argtypes = [vp, vp]
         lib.mis_triangulate.argtypes = [vp, vp, vp, vp, i32, vp]
         lib.mis_triangulate_device.argtypes = [vp, vp, vp, vp, i32, vp]
+        lib.mis_disparity_map.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp]
+        lib.mis_write_xyz.argtypes = [C.c_char_p, vp, i32, vp, i32, i32]
+        lib.mis_rasterize_leaves.argtypes = [vp, i32, i32, i32, vp]
         lib.mis_profile_enable.argtypes = [vp, i32]
         lib.mis_profile_read.argtypes = [vp, vp, vp, vp, vp]
         lib.mis_triangulate_disparity_device.argtypes = [vp, vp, vp, vp, vp, f32, vp, vp]
@@ -113,6 +130,37 @@ def make_camera(A, R, T):
     cam.R[:] = [float(v) for v in np.asarray(R, np.float32).reshape(9)]
     cam.T[:] = [float(v) for v in np.asarray(T, np.float32).reshape(3)]
     return cam
+
+
+def write_xyz(path, xyz, bands=None, append=False):
+    """XYZ text file in the reference's format (image3.cpp:842-849)."""
+    lib = load_library()
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    nb = 0
+    if bands is not None:
+        bands = np.ascontiguousarray(bands, np.float32).reshape(xyz.shape[0], -1)
+        nb = bands.shape[1]
+    rc = lib.mis_write_xyz(os.fsencode(path), _np_ptr(xyz), xyz.shape[0], _np_ptr(bands) if nb else None, nb,
+                           1 if append else 0)
+    if rc != 0:
+        raise MisError(rc, "mis_write_xyz failed for %s" % path)
+
+
+def rasterize_leaves(records, width, height, fill=0.0):
+    """The three bands of the reference's disparity GeoTIFF (image3.cpp:853-860) -> [3, H, W]."""
+    lib = load_library()
+    n = len(records)
+    arr = (Leaf * max(n, 1))()
+    for i, r in enumerate(records):
+        arr[i].bbox1 = Rect(*r[0:4])
+        arr[i].total_dx, arr[i].total_dy = r[4], r[5]
+        arr[i].u1, arr[i].v1, arr[i].u2, arr[i].v2 = r[6:10]
+        arr[i].peak = r[10]
+    out = np.full((3, height, width), fill, np.float32)
+    rc = lib.mis_rasterize_leaves(arr, n, width, height, _np_ptr(out))
+    if rc != 0:
+        raise MisError(rc, "mis_rasterize_leaves failed")
+    return out
 
 
 def _rects(rects):
@@ -260,6 +308,18 @@ class Context:
         out = np.empty((h, w), np.uint8)
         self._check(self._lib.mis_xcorr_surface_u8(self._h, _np_ptr(out)))
         return out
+
+    # ---- coarse-to-fine driver ----
+    def disparity_map(self, min_size=32, max_leaves=1 << 16):
+        """calcDisparityMap (image3.cpp:676) for the bound pair -> (leaf records, findOffset count).
+        Records: (minx, miny, w, h, total_dx, total_dy, u1, v1, u2, v2, peak), depth-first order."""
+        h, w = self.shape
+        leaves = (Leaf * max_leaves)()
+        n, nt = C.c_int(0), C.c_int(0)
+        self._check(self._lib.mis_disparity_map(self._h, w, h, min_size, leaves, max_leaves, C.byref(n), C.byref(nt)))
+        recs = [(l.bbox1.minx, l.bbox1.miny, l.bbox1.width, l.bbox1.height, l.total_dx, l.total_dy,
+                 l.u1, l.v1, l.u2, l.v2, l.peak) for l in leaves[:min(n.value, max_leaves)]]
+        return recs, nt.value
 
     # ---- triangulation ----
     def calculate_xyz(self, cam1, cam2, pts):

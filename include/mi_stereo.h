@@ -133,6 +133,33 @@ int mis_triangulate_disparity_device(mis_ctx* ctx, const mis_camera* c1, const m
                                      const float* d_disp, const float* d_peak, float min_peak,
                                      float* d_xyz, long long* n_matched);
 
+/* ---- coarse-to-fine driver and output records (host code above the kernels) -------------------
+ * One leaf of the tile recursion: what calcDisparityMap hands to its outputs (image3.cpp:812-861). */
+typedef struct {
+    mis_rect bbox1;              /* leaf tile in image 1 (the area written to the disparity raster) */
+    int32_t total_dx, total_dy;  /* image3.cpp:698-699 */
+    int32_t u1, v1, u2, v2;      /* matched pixel pair handed to calculateXYZ (image3.cpp:815-818) */
+    float peak;                  /* correlation peak of the leaf's tile */
+} mis_leaf;
+
+/* calcDisparityMap (image3.cpp:676-865) for the bound pair, level-synchronous instead of
+ * depth-first: every recursion level is one batched mis_xcorr_tiles call per tile size.  Leaves
+ * come back in the reference's depth-first visiting order.  *n_leaves is the total even when it
+ * exceeds max_leaves; *n_tiles (nullable) counts findOffset evaluations.  The first level's tile
+ * is the whole raster and must have power-of-two sides (MIS_ERR_UNSUPPORTED otherwise); "no
+ * overlap" (image3.cpp:710-712) returns MIS_ERR_STATE. */
+int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_size,
+                      mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles);
+
+/* XYZ text file of image3.cpp:842-849: "%f %f %f " then one "%f " per band, newline; the format
+ * xyz2pcd/xyzrgb2pcd.cpp:49 and xyz2geojson/*.rb read.  bands: n x n_bands samples (nullable). */
+int mis_write_xyz(const char* path, const float* xyz, int n, const float* bands, int n_bands, int append);
+
+/* The three Float32 bands of the reference's disparity GeoTIFF (image3.cpp:853-860, 872-893):
+ * sqrtf(tx*tx+ty*ty), tx, ty, each leaf stretched over its bbox1; out = 3 planes of
+ * width*height floats (INTERLEAVE=BAND). */
+int mis_rasterize_leaves(const mis_leaf* leaves, int n, int width, int height, float* out);
+
 /* ---- device timing (no counterpart in the reference, which has no timing code) ----------------
  * While enabled, every dense-NCC call records HIP events on the context's stream around its
  * table-building kernels, its main correlation (argmax) kernel and its refinement kernel.

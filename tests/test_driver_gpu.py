@@ -1,0 +1,71 @@
+"""Coarse-to-fine driver (calcDisparityMap, image3.cpp:676-865): the level-synchronous product
+driver against the oracle's depth-first restatement, plus the XYZ / disparity-raster writers."""
+import os
+
+import numpy as np
+import pytest
+
+import mistereo
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _shifted_pair(size, dx, dy, seed):
+    big = synth.texture(size + 2 * abs(dy) + 8, size + 2 * abs(dx) + 8, seed)
+    oy, ox = abs(dy) + 4, abs(dx) + 4
+    img2 = np.ascontiguousarray(big[oy:oy + size, ox:ox + size])
+    img1 = np.ascontiguousarray(big[oy - dy:oy - dy + size, ox - dx:ox - dx + size])
+    return img1, img2
+
+
+@pytest.mark.parametrize("size,dx,dy,min_size", [(256, 0, 0, 32), (512, 13, -6, 32), (512, -40, 25, 64), (256, 7, 3, 16)])
+def test_leaves_match_the_depth_first_reference_order(ctx, size, dx, dy, min_size):
+    img1, img2 = _shifted_pair(size, dx, dy, 300 + size + dx)
+    ctx.upload_pair(img1, img2)
+    got, ntiles = ctx.disparity_map(min_size=min_size)
+    want, ncalls = oracle.disparity_map(img1, img2, min_size=min_size, precision=1)
+    assert ntiles == ncalls
+    assert len(got) == len(want) > 0
+    for g, w in zip(got, want):
+        assert g[:10] == w[:10]                      # boxes, offsets and matched pixels, in order
+        assert abs(g[10] - w[10]) <= 1e-4 * max(abs(w[10]), 1e-3) + 1e-5
+    if dx or dy:
+        inner = [g for g in got if g[10] > 0.75]
+        assert inner and all((g[4], g[5]) == (dx, dy) for g in inner)
+
+
+def test_zero_shift_counts(ctx):
+    """2048-px pair, zero shift, min_size 32: 1 + 4 + 16 + 64 + 256 + 1024 = 1365 evaluations and
+    1024 leaves, the count the reference makes for BASELINE config[0]."""
+    img = synth.texture(2048, 2048, 11)
+    ctx.upload_pair(img, img)
+    got, ntiles = ctx.disparity_map(min_size=32, max_leaves=4096)
+    assert ntiles == 1365 and len(got) == 1024
+    assert all(g[2] == 64 and g[4] == 0 and g[5] == 0 for g in got)
+
+
+def test_xyz_file_and_disparity_bands(ctx, tmp_path):
+    img1, img2 = _shifted_pair(256, 9, -4, 77)
+    ctx.upload_pair(img1, img2)
+    leaves, _ = ctx.disparity_map(min_size=32)
+    A = [[10000, 0, 128], [0, 10000, 128], [0, 0, 1]]
+    c1 = mistereo.make_camera(A, np.eye(3), [0, 0, -3000])
+    c2 = mistereo.make_camera(A, np.eye(3), [-900, 0, -3000])
+    pts = np.array([l[6:10] for l in leaves], np.int32)
+    xyz = ctx.calculate_xyz(c1, c2, pts)
+    bands = np.array([[float(img1[l[7], l[6]])] for l in leaves], np.float32)
+    path = os.path.join(tmp_path, "out.xyz")
+    mistereo.write_xyz(path, xyz, bands)
+    lines = open(path).read().splitlines()
+    assert len(lines) == len(leaves)
+    for ln, p, b in zip(lines, xyz, bands):
+        assert ln == "%f %f %f %f " % (p[0], p[1], p[2], b[0])     # image3.cpp:842-849
+        assert len(ln.split()) == 4                                  # what xyz2pcd's sscanf reads
+    ras = mistereo.rasterize_leaves(leaves, 256, 256, fill=-1.0)
+    # later leaves overwrite earlier ones where clamped tiles overlap: check the last writer
+    last = leaves[-1]
+    cx, cy = last[0] + last[2] // 2, last[1] + last[3] // 2
+    assert ras[1, cy, cx] == last[4] and ras[2, cy, cx] == last[5]
+    assert ras[0, cy, cx] == np.float32(np.sqrt(np.float32(last[4] * last[4] + last[5] * last[5])))

@@ -1,0 +1,135 @@
+"""Host-side logic that needs no GPU: synthetic generators, output writers, work partition and the
+rank-0 gather (world_size 2 over gloo)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import mistereo
+import partition
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_synth_is_deterministic_and_in_range():
+    a = synth.texture(64, 96, 0xC0FFEE)
+    b = synth.texture(64, 96, 0xC0FFEE)
+    assert np.array_equal(a, b) and a.min() >= 16 and a.max() <= 240
+    assert synth.splitmix64(1, 3).tolist() == [10451216379200822465, 13757245211066428519, 17911839290282890590]
+    r = synth.shift_right_image(a, 5, fill_seed=2)
+    assert np.array_equal(r[:, :-5], a[:, 5:])               # right(x') = left(x' + d)
+    u16 = synth.texture(32, 32, 3, np.uint16)
+    assert u16.dtype == np.uint16 and u16.max() > 255
+
+
+def test_write_xyz_format(tmp_path):
+    xyz = np.array([[1.5, -2.25, 3.0], [1e6, 0.1, -7.125]], np.float32)
+    bands = np.array([[10, 20, 30], [255, 0, 1]], np.float32)
+    p = os.path.join(tmp_path, "a.xyz")
+    mistereo.write_xyz(p, xyz, bands)
+    mistereo.write_xyz(p, xyz[:1], bands[:1], append=True)
+    lines = open(p).read().split("\n")
+    assert lines[0] == "1.500000 -2.250000 3.000000 10.000000 20.000000 30.000000 "   # image3.cpp:842-849
+    assert lines[1] == "%f %f %f %f %f %f " % (1e6, np.float32(0.1), -7.125, 255, 0, 1)
+    assert lines[2] == lines[0] and lines[3] == ""
+    # 7 floats per line is what xyzrgb2pcd.cpp:49 parses when the raster has 4 bands
+    mistereo.write_xyz(p, xyz, None)
+    assert open(p).read().split("\n")[0] == "1.500000 -2.250000 3.000000 "
+
+
+def test_rasterize_leaves():
+    leaves = [(0, 0, 4, 4, 3, 4, 0, 0, 0, 0, 0.9), (2, 2, 4, 4, -1, 0, 0, 0, 0, 0, 0.8)]
+    ras = mistereo.rasterize_leaves(leaves, 8, 8, fill=-9.0)
+    assert ras[0, 0, 0] == 5.0 and ras[1, 0, 0] == 3 and ras[2, 0, 0] == 4      # sqrtf(9+16), tx, ty
+    assert ras[0, 3, 3] == 1.0 and ras[1, 3, 3] == -1                          # the later leaf overwrites
+    assert ras[0, 7, 7] == -9.0                                                # untouched
+
+
+@pytest.mark.parametrize("h,world", [(8192, 8), (100, 3), (5, 8), (16384, 2)])
+def test_row_strips_cover_the_frame_once(h, world):
+    strips = partition.row_strips(h, world)
+    assert len(strips) == world and sum(n for _, n in strips) == h
+    row = 0
+    for r0, n in strips:
+        assert r0 == row
+        row += n
+    lo, n = partition.strip_input_rows(*strips[-1], h, 21)
+    assert lo + n <= h and lo >= 0
+    assert partition.frames_for_rank(16, 3, 8) == [3, 11]
+
+
+def _gloo_worker(rank, world, port, h, w, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(h * w, dtype=torch.float32).reshape(h, w)      # stands for a disparity raster
+        strips = partition.row_strips(h, world)
+        r0, n = strips[rank]
+        out = partition.gather_rows(full[r0:r0 + n].clone(), strips, rank, world)
+        if rank == 0:
+            q.put(bool(torch.equal(out, full)))
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_rows_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, 37, 16, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def _pipeline_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bufs = [torch.zeros((2, 8, 8)) for _ in range(2)]
+        pipe = bench.GatherPipeline(rank, world, bufs)
+        ok = True
+        for step in range(5):                       # the bench loop: reuse, compute, submit
+            b = step % 2
+            pipe.reuse(b)
+            bufs[b].fill_(100 * step + rank)
+            pipe.submit(b)
+        pipe.drain()
+        if rank == 0:
+            # the last two steps' gathers are still in the buffers
+            for step in (3, 4):
+                for r in range(world):
+                    ok = ok and bool((pipe.gathered[step % 2][r] == 100 * step + r).all())
+            q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_gather_pipeline_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

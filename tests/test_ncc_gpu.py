@@ -59,3 +59,22 @@ def test_too_small_frame_is_all_invalid(ctx):
     ctx.upload_pair(left, left)
     out = ctx.ncc_dense(15, -4, 4)
     assert np.all(out["idisp"] == -32768) and np.all(out["peak"] == 0)
+
+
+def test_row_strips_equal_the_full_frame(ctx):
+    """Two row strips computed separately (the multi-GPU partition) equal the full-frame result."""
+    import torch
+    import partition
+    left = synth.texture(90, 300, 21)
+    right = synth.shift_right_image(left, -12, fill_seed=22)
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    ctx.bind_pair_torch(tl, tr)
+    full_d = torch.empty((90, 300), dtype=torch.float32, device="cuda")
+    full_p = torch.empty_like(full_d)
+    ctx.ncc_dense_torch(11, -40, 40, full_d, full_p)
+    part_d = torch.full_like(full_d, 12345.0)
+    part_p = torch.full_like(full_d, 12345.0)
+    for row0, n in partition.row_strips(90, 3):
+        ctx.ncc_dense_torch(11, -40, 40, part_d, part_p, row0=row0, nrows=n)
+    ctx.synchronize()
+    assert torch.equal(full_d, part_d) and torch.equal(full_p, part_p)
