@@ -25,6 +25,8 @@ struct mis_ctx {
 
     // dense-NCC workspace (see ncc_kernels.hip)
     struct NccWs* ncc = nullptr;
+    // 16-bit dense-NCC workspace (see ncc16_kernels.hip)
+    struct Ncc16Ws* ncc16 = nullptr;
     // FFT-correlation workspace (see xcorr_kernels.hip)
     struct XcorrWs* xc = nullptr;
     // optional per-call device timing of the dense-NCC kernels (mis_profile_*)
@@ -52,6 +54,7 @@ int mis_reserve(mis_ctx* ctx, void** buf, size_t* cap, size_t bytes);
 hipEvent_t mis_prof_mark(mis_ctx* ctx);
 
 void mis_ncc_release(mis_ctx* ctx);
+void mis_ncc16_release(mis_ctx* ctx);
 void mis_xcorr_release(mis_ctx* ctx);
 
 static inline int mis_pixel_bytes(int dtype)

@@ -116,6 +116,7 @@ int mis_destroy(mis_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     mis_ncc_release(ctx);
+    mis_ncc16_release(ctx);
     mis_xcorr_release(ctx);
     if (ctx->tri_buf) (void)hipFree(ctx->tri_buf);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);

@@ -1,0 +1,362 @@
+// Dense windowed NCC for 16-bit rasters, gfx950: the same lane <-> disparity walk and batched
+// argmax as the 8-bit path (ncc_kernels.hip), with exact 64-bit integer sums instead of the
+// f16/f32 trick: a product of two 16-bit pixels needs 31 bits and a 31x31 window sum 41.
+//   column sums and window sums: int64, updated with v_mad_i64_i32
+//   num = N*S_LR - S_L*S_R exactly (int64), score = float(num) * (1/sqrt(N var_L)) * (1/sqrt(N var_R))
+// Pixels are shifted by 32768 into int16 range first.  Slower than the 8-bit path (quarter-rate
+// 64-bit multiplies), exact like the oracle.  Definition: see mi_stereo.h (dense windowed NCC).
+#include "ncc_shared.h"
+
+#include <math.h>
+
+struct Ncc16Ws {
+    int32_t *L32 = nullptr, *R32 = nullptr;     // shifted rasters, pitch P
+    int32_t *SL = nullptr, *SR = nullptr;       // window sums of the shifted pixels
+    float *iL = nullptr, *iR = nullptr;         // 1/sqrt(N*sum sq - sum^2); iR NaN where the window does not fit
+    int32_t* hs1 = nullptr; long long* hs2 = nullptr;
+    float* keys = nullptr; size_t keys_bytes = 0;
+    size_t cap_px = 0;
+    int pitch = 0, rows = 0, window = 0;
+    uint64_t pair_serial = 0;
+};
+
+void mis_ncc16_release(mis_ctx* ctx)
+{
+    Ncc16Ws* w = ctx->ncc16;
+    if (!w) return;
+    void* bufs[] = { w->L32, w->R32, w->SL, w->SR, w->iL, w->iR, w->hs1, w->hs2, w->keys };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    delete w;
+    ctx->ncc16 = nullptr;
+}
+
+__global__ __launch_bounds__(256) void ncc16_hsum_kernel(const uint16_t* __restrict__ img, size_t stride_px,
+                                                         int W, int H, int r, int pitch, int32_t* __restrict__ p32,
+                                                         int32_t* __restrict__ hs1, long long* __restrict__ hs2)
+{
+    __shared__ int tile[256 + 2 * 16];
+    const int y = blockIdx.y, x0 = blockIdx.x * 256;
+    const uint16_t* row = img + (size_t)y * stride_px;
+    for (int i = threadIdx.x; i < 256 + 2 * r; i += 256) {
+        int x = x0 - r + i;
+        tile[i] = (x >= 0 && x < W) ? (int)row[x] - 32768 : 0;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= pitch) return;
+    int s1 = 0; long long s2 = 0;
+    for (int i = 0; i <= 2 * r; i++) { int v = tile[threadIdx.x + i]; s1 += v; s2 += (long long)v * v; }
+    const size_t o = (size_t)y * pitch + x;
+    p32[o] = tile[threadIdx.x + r];
+    hs1[o] = s1; hs2[o] = s2;
+}
+
+#define NCC16_STATS_BAND 128
+template <bool LEFT>
+__global__ __launch_bounds__(256) void ncc16_stats_kernel(int W, int H, int r, int pitch,
+                                                          const int32_t* __restrict__ hs1, const long long* __restrict__ hs2,
+                                                          int32_t* __restrict__ osum, float* __restrict__ oinv)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= pitch) return;
+    const int y0 = blockIdx.y * NCC16_STATS_BAND, y1 = min(y0 + NCC16_STATS_BAND, H);
+    const long long N = (long long)(2 * r + 1) * (2 * r + 1);
+    const bool colok = (x >= r && x < W - r);
+    long long s1 = 0, s2 = 0;
+    bool have = false;
+    for (int y = y0; y < y1; y++) {
+        const size_t o = (size_t)y * pitch + x;
+        int vs = 0;
+        float vi = LEFT ? 0.f : (colok ? 0.f : __builtin_nanf(""));
+        if (colok && y >= r && y < H - r) {
+            if (!have) {
+                s1 = 0; s2 = 0;
+                for (int j = -r; j <= r; j++) { s1 += hs1[(size_t)(y + j) * pitch + x]; s2 += hs2[(size_t)(y + j) * pitch + x]; }
+                have = true;
+            } else {
+                s1 += hs1[(size_t)(y + r) * pitch + x] - hs1[(size_t)(y - r - 1) * pitch + x];
+                s2 += hs2[(size_t)(y + r) * pitch + x] - hs2[(size_t)(y - r - 1) * pitch + x];
+            }
+            const long long var = N * s2 - s1 * s1;
+            vs = (int)s1;
+            vi = var > 0 ? (float)(1.0 / sqrt((double)var)) : 0.f;
+        }
+        if (LEFT) { if (x >= r) { osum[o - r] = vs; oinv[o - r] = vi; } }     // left tables shifted by r (see ncc_kernels.hip)
+        else { osum[o] = vs; oinv[o] = vi; }
+    }
+}
+
+template <int R, int WT>
+struct Ncc16Cfg {
+    static constexpr int NC = WT + 2 * R;
+    static constexpr int NCP = (NC + 3) & ~3;
+    static constexpr int SEG = NCP + 64 + 4;
+    static constexpr int LENP = ((SEG + 3 + 47) / 64) * 64 + 16;
+};
+
+// One wavefront per workgroup = (strip of WT columns, band of rows, chunk of 64 disparities).
+// LDS: 4 arrays (entering right row, leaving right row, S_R, 1/sigma_R) x 4 shifted copies.
+template <int R, int WT>
+__global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
+    NccArgs a, const int32_t* __restrict__ gL, const int32_t* __restrict__ gR,
+    const int32_t* __restrict__ gSL, const int32_t* __restrict__ gSR, const float* __restrict__ gIR,
+    float* __restrict__ oKeys)
+{
+    using Cfg = Ncc16Cfg<R, WT>;
+    constexpr int WN = 2 * R + 1, NC = Cfg::NC, NCP = Cfg::NCP, SEG = Cfg::SEG, LENP = Cfg::LENP;
+    constexpr long long NN = (long long)WN * WN;
+    __shared__ __attribute__((aligned(16))) int sArr[16 * LENP];
+
+    const int lane = threadIdx.x;
+    int chunk, strip, band;
+    {
+        const int total = a.nstrips * a.nbands * a.nchunk;
+        const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
+        const int q = total >> 3, rem = total & 7;
+        const int wid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+        chunk = wid % a.nchunk;
+        strip = (wid / a.nchunk) % a.nstrips;
+        band = wid / (a.nchunk * a.nstrips);
+    }
+    const int x0 = R + strip * WT;
+    const int yb0 = a.row0 + band * a.band_rows;
+    const int yb1 = min(yb0 + a.band_rows, a.row1);
+    if (yb0 >= yb1) return;
+    const int T = 2 * R + (yb1 - yb0);
+    const int dtop = a.dmin + chunk * 64 + 63;
+    const int d = dtop - 63 + lane;
+    const int loff = 63 - lane;
+    const int xr0 = x0 - R - dtop;
+    const float bias = (d <= a.dmax) ? 0.f : -3.0e38f;
+    const uint32_t tag = 63u - (uint32_t)lane;
+    const int cA = loff & 3, offB = loff + R, cB = offB & 3;
+    const int P = a.pitch;
+
+    int mycol;
+    {
+        float qi[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            NccTree tr;
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) tr.push(jj, (float)(b * 16 + jj));
+            qi[b] = tr.q;
+        }
+        mycol = (int)ncc_reduce_quads(qi[0], qi[1], qi[2], qi[3], lane);
+    }
+
+    long long C[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) C[k] = 0;
+
+    auto stage = [&](int ynew, int yout, bool stats, bool warm) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int i = lane + 64 * q;
+            if (i >= SEG) continue;
+            const int xr = xr0 + i;
+            const bool in = (xr >= 0 && xr < a.W);
+            const int yold = ynew - WN;
+            const int vn = in ? gR[(size_t)ynew * P + xr] : 0;
+            const int vo = (in && !warm && yold >= 0) ? gR[(size_t)yold * P + xr] : 0;
+            const int vs = (stats && in) ? gSR[(size_t)yout * P + xr] : 0;
+            const float vi = stats ? (in ? gIR[(size_t)yout * P + xr] : __builtin_nanf("")) : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int pos = i + ((4 - c) & 3);
+                sArr[(0 * 4 + c) * LENP + pos] = vn;
+                sArr[(1 * 4 + c) * LENP + pos] = vo;
+                sArr[(2 * 4 + c) * LENP + pos] = vs;
+                sArr[(3 * 4 + c) * LENP + pos] = __builtin_bit_cast(int, vi);
+            }
+        }
+    };
+
+    for (int t = 0; t < T; t++) {
+        const int ynew = yb0 - R + t;
+        const bool warm = (t < WN);
+        const bool score = (t >= 2 * R);
+        const int yout = ynew - R;
+        stage(ynew, yout, score, warm);
+        // a wavefront's LDS operations execute in order: the reads below see the row just written
+
+        const int4* bn4 = (const int4*)(sArr + (0 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
+        const int4* bo4 = (const int4*)(sArr + (1 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
+        const int32_t* lnew = gL + (size_t)ynew * P + (x0 - R);
+        const int yold = ynew - WN;
+        const int32_t* lold = gL + (size_t)(yold >= 0 ? yold : 0) * P + (x0 - R);
+        const bool use_old = !warm && yold >= 0;
+#pragma unroll
+        for (int kb = 0; kb < NCP / 4; kb++) {
+            const int4 bn = bn4[kb], bo = bo4[kb];
+            const int bnv[4] = { bn.x, bn.y, bn.z, bn.w }, bov[4] = { bo.x, bo.y, bo.z, bo.w };
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int k = 4 * kb + e;
+                if (k < NC) {
+                    const int an = lnew[k];
+                    const int ao = use_old ? -lold[k] : 0;
+                    C[k] += (long long)an * bnv[e];
+                    C[k] += (long long)ao * bov[e];
+                }
+            }
+        }
+
+        if (score) {
+            const int4* sr4 = (const int4*)(sArr + (2 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
+            const float4* ir4 = (const float4*)(sArr + (3 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
+            const int32_t* slrow = gSL + (size_t)yout * P + (x0 - R);
+            long long S = 0;
+#pragma unroll
+            for (int k = 0; k < 2 * R; k++) S += C[k];
+            float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
+            NccTree tr;
+#pragma unroll
+            for (int g = 0; g < WT / 4; g++) {
+                const int4 s4 = sr4[g];
+                const float4 i4 = ir4[g];
+                const int srv[4] = { s4.x, s4.y, s4.z, s4.w };
+                const float irv[4] = { i4.x, i4.y, i4.z, i4.w };
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int j = 4 * g + e;
+                    S += C[j + 2 * R];
+                    const long long num = NN * S - (long long)slrow[j] * (long long)srv[e];   // exact
+                    const float sc = __builtin_fmaf((float)num, irv[e], bias);
+                    S -= C[j];
+                    tr.push(j & 15, ncc_make_key(sc, tag));
+                }
+                if ((g & 3) == 3) q[g >> 2] = tr.q;
+            }
+            const float red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
+            const int x = x0 + mycol;
+            if (mycol < WT && x < a.W - R)
+                oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red;
+        }
+    }
+}
+
+// merge of the chunk keys, exact scores of the winner and its neighbours by direct window sums
+template <int R>
+__global__ __launch_bounds__(256) void ncc16_refine_kernel(
+    NccArgs a, const int32_t* __restrict__ gL, const int32_t* __restrict__ gR,
+    const int32_t* __restrict__ gSL, const float* __restrict__ gIL, const int32_t* __restrict__ gSR,
+    const float* __restrict__ gIR, const float* __restrict__ gKeys, int nchunk,
+    float* __restrict__ oDisp, float* __restrict__ oPeak, int16_t* __restrict__ oIdisp)
+{
+    const int x = R + blockIdx.x * 256 + threadIdx.x;
+    const int y = a.row0 + blockIdx.y;
+    if (x >= a.W - R) return;
+    const int P = a.pitch;
+    const size_t o = (size_t)y * a.out_pitch + x;
+    int ds = MIS_INVALID_DISP;
+    {
+        float best = -1.0e30f;
+        for (int c = 0; c < nchunk; c++) {
+            const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * a.H * a.out_pitch + o]);
+            const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
+            if (v > best) { best = v; ds = a.dmin + c * 64 + 63 - (int)(kb & 63u); }
+        }
+    }
+    if (oIdisp) oIdisp[o] = (int16_t)ds;
+    if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; return; }
+    const int u = x - ds;
+    long long Sm = 0, S0 = 0, Sp = 0;            // disparities ds-1, ds, ds+1 <-> right columns u+1, u, u-1
+    for (int j = -R; j <= R; j++) {
+        const int32_t* lr = gL + (size_t)(y + j) * P;
+        const int32_t* rr = gR + (size_t)(y + j) * P;
+        for (int i = -R; i <= R; i++) {
+            const long long l = lr[x + i];
+            const int c0 = u + i;
+            Sm += l * rr[min(max(c0 + 1, 0), P - 1)];
+            S0 += l * rr[min(max(c0, 0), P - 1)];
+            Sp += l * rr[min(max(c0 - 1, 0), P - 1)];
+        }
+    }
+    constexpr long long NN = (long long)(2 * R + 1) * (2 * R + 1);
+    const long long sl = gSL[(size_t)y * P + (x - R)];
+    const float il = gIL[(size_t)y * P + (x - R)];
+    auto score = [&](long long S, int col, int d) -> float {
+        if (d < a.dmin || d > a.dmax || col < 0 || col >= a.W) return __builtin_nanf("");
+        const long long num = NN * S - sl * (long long)gSR[(size_t)y * P + col];
+        return __builtin_fmaf((float)num, gIR[(size_t)y * P + col], 0.f);
+    };
+    const float sm = score(Sm, u + 1, ds - 1), s0 = score(S0, u, ds), sp = score(Sp, u - 1, ds + 1);
+    float delta = 0.f;
+    if (sm == sm && sp == sp) {
+        const float den = 2.f * (sm - 2.f * s0 + sp);
+        if (den != 0.f) delta = fminf(0.5f, fmaxf(-0.5f, (sm - sp) / den));
+    }
+    oDisp[o] = (float)ds + delta;
+    oPeak[o] = s0 * il;
+}
+
+static int ncc16_prepare(mis_ctx* ctx, int window)
+{
+    Ncc16Ws* w = ctx->ncc16;
+    if (!w) { w = new Ncc16Ws(); ctx->ncc16 = w; }
+    const int W = ctx->width, H = ctx->height, r = window / 2;
+    const int pitch = ((W + 64 + 63) / 64) * 64 + 64;
+    const size_t npx = (size_t)pitch * H;
+    if (w->cap_px < npx) {
+        void** b4[] = { (void**)&w->L32, (void**)&w->R32, (void**)&w->SL, (void**)&w->SR, (void**)&w->iL, (void**)&w->iR,
+                        (void**)&w->hs1 };
+        for (void** b : b4) { if (*b) { MIS_HIP(ctx, hipFree(*b)); *b = nullptr; } }
+        if (w->hs2) { MIS_HIP(ctx, hipFree(w->hs2)); w->hs2 = nullptr; }
+        w->cap_px = 0;
+        for (void** b : b4) MIS_HIP(ctx, hipMalloc(b, npx * 4));
+        MIS_HIP(ctx, hipMalloc((void**)&w->hs2, npx * 8));
+        w->cap_px = npx;
+        w->pair_serial = 0;
+    }
+    if (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H) return MIS_OK;
+    w->pitch = pitch; w->rows = H;
+    dim3 grid((pitch + 255) / 256, H), block(256);
+    dim3 sgrid((pitch + 255) / 256, (H + NCC16_STATS_BAND - 1) / NCC16_STATS_BAND);
+    hipStream_t s = ctx->stream;
+    const size_t stride_px = ctx->stride / 2;
+    hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[0], stride_px, W, H, r, pitch, w->L32, w->hs1, w->hs2);
+    hipLaunchKernelGGL(ncc16_stats_kernel<true>, sgrid, block, 0, s, W, H, r, pitch, w->hs1, w->hs2, w->SL, w->iL);
+    hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[1], stride_px, W, H, r, pitch, w->R32, w->hs1, w->hs2);
+    hipLaunchKernelGGL(ncc16_stats_kernel<false>, sgrid, block, 0, s, W, H, r, pitch, w->hs1, w->hs2, w->SR, w->iR);
+    MIS_HIP(ctx, hipGetLastError());
+    w->pair_serial = ctx->pair_serial;
+    w->window = window;
+    return MIS_OK;
+}
+
+template <int R>
+static int ncc16_launch(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
+{
+    constexpr int WT = 32;
+    Ncc16Ws* w = ctx->ncc16;
+    int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, (size_t)a.nchunk * a.H * a.W * sizeof(float));
+    if (rc) return rc;
+    a.nstrips = (a.W - 2 * R + WT - 1) / WT;
+    a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
+    hipLaunchKernelGGL((ncc16_argmax_kernel<R, WT>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
+                       a, w->L32, w->R32, w->SL, w->SR, w->iR, w->keys);
+    mis_prof_mark(ctx);
+    hipLaunchKernelGGL(ncc16_refine_kernel<R>, dim3((a.W - 2 * R + 255) / 256, a.row1 - a.row0), dim3(256), 0, ctx->stream,
+                       a, w->L32, w->R32, w->SL, w->iL, w->SR, w->iR, w->keys, a.nchunk, d_disp, d_peak, d_idisp);
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+// called by the dense-NCC entry points for 16-bit pairs; a: geometry already filled in
+int mis_ncc16_run(mis_ctx* ctx, int window, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
+{
+    int rc = ncc16_prepare(ctx, window);
+    if (rc) return rc;
+    a.pitch = ctx->ncc16->pitch;
+    mis_prof_mark(ctx);
+#define NCC16_CASE(RR) case RR: rc = ncc16_launch<RR>(ctx, a, d_disp, d_peak, d_idisp); break;
+    switch (window / 2) {
+        NCC16_CASE(1) NCC16_CASE(2) NCC16_CASE(3) NCC16_CASE(4) NCC16_CASE(5) NCC16_CASE(6) NCC16_CASE(7) NCC16_CASE(8)
+        NCC16_CASE(9) NCC16_CASE(10) NCC16_CASE(11) NCC16_CASE(12) NCC16_CASE(13) NCC16_CASE(14) NCC16_CASE(15)
+        default: rc = mis_fail(ctx, MIS_ERR_ARG, "dense NCC: unsupported window %d", window);
+    }
+#undef NCC16_CASE
+    mis_prof_mark(ctx);
+    return rc;
+}

@@ -19,12 +19,10 @@
 //
 // Exactness: pixels are shifted by 128 into [-128,127] (NCC does not change); every product,
 // column sum and window sum is an integer below 2^24 and therefore exact in f32.
-#include "mis_common.h"
+#include "ncc_shared.h"
 
 #include <math.h>
 #include <stdio.h>
-
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 struct NccWs {
     // per-pixel tables, pitch P elements per row, H rows
@@ -184,14 +182,6 @@ __global__ __launch_bounds__(256) void ncc_vpack_kernel(const T* __restrict__ im
 // ---------------------------------------------------------------------------------------------
 // Main kernel
 // ---------------------------------------------------------------------------------------------
-struct NccArgs {
-    int W, H, pitch;
-    int dmin, dmax, nchunk;
-    int row0, row1;      // output rows [row0,row1), already clipped to [r, H-r)
-    int band_rows;       // rows per workgroup
-    int out_pitch;       // elements per output row (== W)
-    int nstrips, nbands; // fast path: work decomposition (strips of columns, bands of rows)
-};
 
 #define DPP_QUAD_1032 0xB1
 #define DPP_QUAD_2301 0x4E
@@ -472,76 +462,6 @@ __global__ __launch_bounds__(1024) void ncc_main_kernel(
 // of a dependent 6-step reduction per column.  The chunk wavefronts of a workgroup then merge
 // their keys through LDS.
 // ---------------------------------------------------------------------------------------------
-#define NCC_DPP_MAX(dst, src, mods) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " mods : "+v"(dst) : "v"(src))
-
-__device__ __forceinline__ float vmax_raw(float a, float b)
-{
-    float r;
-    asm volatile("s_nop 1\n\tv_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // NaN operands are ignored
-    return r;
-}
-
-// ---- transposing max network, fed one column at a time ----
-__device__ __forceinline__ float ncc_merge32(float a, float b)
-{
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return vmax_raw(a, b);        // lanes 0-31: column of a, lanes 32-63: column of b
-}
-__device__ __forceinline__ float ncc_merge16(float a, float b)
-{
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return vmax_raw(a, b);        // rows 0,2 from a, rows 1,3 from b
-}
-__device__ __forceinline__ float ncc_merge8(float a, float b)
-{
-    float o = a;
-    NCC_DPP_MAX(o, a, "row_ror:8 row_mask:0xf bank_mask:0xf");
-    NCC_DPP_MAX(o, b, "row_ror:8 row_mask:0xf bank_mask:0xc");
-    return o;                     // lanes 0-7 of every row from a, lanes 8-15 from b
-}
-__device__ __forceinline__ float ncc_merge4(float a, float b)
-{
-    float o = a;
-    NCC_DPP_MAX(o, a, "row_shl:4 row_mask:0xf bank_mask:0x5");
-    NCC_DPP_MAX(o, b, "row_shr:4 row_mask:0xf bank_mask:0xa");
-    return o;                     // banks 0,2 from a, banks 1,3 from b
-}
-
-// Keys of 16 columns (lane = candidate) -> one register in which every 4-lane bank holds the 4
-// partial maxima of one column.  Columns are pushed one at a time (jj = 0..15, a compile-time
-// constant after unrolling); pairs are merged as soon as both halves exist, so at most five
-// partial registers are alive.
-struct NccTree {
-    float t0, t1, t2, t3, q;
-    __device__ __forceinline__ void push(int jj, float k)
-    {
-        if ((jj & 1) == 0) { t0 = k; return; }
-        const float m1 = ncc_merge32(t0, k);
-        if ((jj & 2) == 0) { t1 = m1; return; }
-        const float m2 = ncc_merge16(t1, m1);
-        if ((jj & 4) == 0) { t2 = m2; return; }
-        const float m3 = ncc_merge8(t2, m2);
-        if ((jj & 8) == 0) { t3 = m3; return; }
-        q = ncc_merge4(t3, m3);
-    }
-};
-
-// four such registers -> one register with 64 column maxima (one per lane)
-__device__ __forceinline__ float ncc_reduce_quads(float q0, float q1, float q2, float q3, int lane)
-{
-    float t0 = q0, t1 = q1, t2 = q2, t3 = q3;
-    NCC_DPP_MAX(t0, q0, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    NCC_DPP_MAX(t1, q1, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    NCC_DPP_MAX(t2, q2, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    NCC_DPP_MAX(t3, q3, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    float e0 = (lane & 2) ? t1 : t0;
-    float e1 = (lane & 2) ? t3 : t2;
-    float u0 = e0, u1 = e1;
-    NCC_DPP_MAX(u0, e0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-    NCC_DPP_MAX(u1, e1, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-    return (lane & 1) ? u1 : u0;
-}
-
 // ---- scheduling fences for the hand-pipelined loops below ----
 // The loops load one group of columns ahead of the arithmetic: wait for everything issued so far
 // (LDS and scalar loads share one counter), issue the next group's loads, then compute.  The
@@ -991,6 +911,22 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
         hipLaunchKernelGGL(ncc_border_kernel, grid, block, 0, ctx->stream, d_disp, d_peak, d_idisp, d_peak2, W, H, r, row0, row0 + nrows);
     }
     if (W < window || H < window) { mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
+    if (ctx->dtype == MIS_U16) {
+        if (d_peak2) return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: the second-peak output is only available for 8-bit rasters");
+        NccArgs a;
+        a.W = W; a.H = H; a.pitch = 0;
+        a.dmin = dmin; a.dmax = dmax;
+        a.row0 = row0 > r ? row0 : r;
+        a.row1 = (row0 + nrows < H - r) ? row0 + nrows : H - r;
+        a.out_pitch = W;
+        a.nstrips = a.nbands = 0;
+        a.nchunk = (dmax - dmin + 1 + 63) / 64;
+        a.band_rows = 128;
+        if (a.row0 >= a.row1) { mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
+        return mis_ncc16_run(ctx, window, a, d_disp, d_peak, d_idisp);
+    }
+    if (ctx->dtype != MIS_U8)
+        return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: 8-bit and 16-bit rasters only");
     int rc = ncc_prepare(ctx, window);
     if (rc) return rc;
     mis_prof_mark(ctx);

@@ -1,0 +1,96 @@
+// Pieces of the dense-NCC kernels shared by the 8-bit (ncc_kernels.hip) and 16-bit
+// (ncc16_kernels.hip) translation units.
+#pragma once
+
+#include "mis_common.h"
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+struct NccArgs {
+    int W, H, pitch;
+    int dmin, dmax, nchunk;
+    int row0, row1;      // output rows [row0,row1), already clipped to [r, H-r)
+    int band_rows;       // rows per workgroup
+    int out_pitch;       // elements per output row (== W)
+    int nstrips, nbands; // fast path: work decomposition (strips of columns, bands of rows)
+};
+
+// 16-bit pairs (ncc16_kernels.hip); a: geometry filled in by the caller except pitch/nstrips/nbands
+int mis_ncc16_run(mis_ctx* ctx, int window, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp);
+
+// key of a score for the batched argmax: upper 26 bits of the float, 63 - lane below
+__device__ __forceinline__ float ncc_make_key(float sc, uint32_t tag)
+{
+    return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, sc) & 0xFFFFFFC0u) | tag);
+}
+
+#define NCC_DPP_MAX(dst, src, mods) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " mods : "+v"(dst) : "v"(src))
+
+__device__ __forceinline__ float vmax_raw(float a, float b)
+{
+    float r;
+    asm volatile("s_nop 1\n\tv_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // NaN operands are ignored
+    return r;
+}
+
+// ---- transposing max network, fed one column at a time ----
+__device__ __forceinline__ float ncc_merge32(float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return vmax_raw(a, b);        // lanes 0-31: column of a, lanes 32-63: column of b
+}
+__device__ __forceinline__ float ncc_merge16(float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return vmax_raw(a, b);        // rows 0,2 from a, rows 1,3 from b
+}
+__device__ __forceinline__ float ncc_merge8(float a, float b)
+{
+    float o = a;
+    NCC_DPP_MAX(o, a, "row_ror:8 row_mask:0xf bank_mask:0xf");
+    NCC_DPP_MAX(o, b, "row_ror:8 row_mask:0xf bank_mask:0xc");
+    return o;                     // lanes 0-7 of every row from a, lanes 8-15 from b
+}
+__device__ __forceinline__ float ncc_merge4(float a, float b)
+{
+    float o = a;
+    NCC_DPP_MAX(o, a, "row_shl:4 row_mask:0xf bank_mask:0x5");
+    NCC_DPP_MAX(o, b, "row_shr:4 row_mask:0xf bank_mask:0xa");
+    return o;                     // banks 0,2 from a, banks 1,3 from b
+}
+
+// Keys of 16 columns (lane = candidate) -> one register in which every 4-lane bank holds the 4
+// partial maxima of one column.  Columns are pushed one at a time (jj = 0..15, a compile-time
+// constant after unrolling); pairs are merged as soon as both halves exist, so at most five
+// partial registers are alive.
+struct NccTree {
+    float t0, t1, t2, t3, q;
+    __device__ __forceinline__ void push(int jj, float k)
+    {
+        if ((jj & 1) == 0) { t0 = k; return; }
+        const float m1 = ncc_merge32(t0, k);
+        if ((jj & 2) == 0) { t1 = m1; return; }
+        const float m2 = ncc_merge16(t1, m1);
+        if ((jj & 4) == 0) { t2 = m2; return; }
+        const float m3 = ncc_merge8(t2, m2);
+        if ((jj & 8) == 0) { t3 = m3; return; }
+        q = ncc_merge4(t3, m3);
+    }
+};
+
+// four such registers -> one register with 64 column maxima (one per lane)
+__device__ __forceinline__ float ncc_reduce_quads(float q0, float q1, float q2, float q3, int lane)
+{
+    float t0 = q0, t1 = q1, t2 = q2, t3 = q3;
+    NCC_DPP_MAX(t0, q0, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    NCC_DPP_MAX(t1, q1, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    NCC_DPP_MAX(t2, q2, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    NCC_DPP_MAX(t3, q3, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    float e0 = (lane & 2) ? t1 : t0;
+    float e1 = (lane & 2) ? t3 : t2;
+    float u0 = e0, u1 = e1;
+    NCC_DPP_MAX(u0, e0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    NCC_DPP_MAX(u1, e1, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    return (lane & 1) ? u1 : u0;
+}
+

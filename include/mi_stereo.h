@@ -152,7 +152,7 @@ int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_s
                       mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles);
 
 /* XYZ text file of image3.cpp:842-849: "%f %f %f " then one "%f " per band, newline; the format
- * xyz2pcd/xyzrgb2pcd.cpp:49 and xyz2geojson/*.rb read.  bands: n x n_bands samples (nullable). */
+ * xyz2pcd/xyzrgb2pcd.cpp:49 and xyz2geojson (its .rb scripts) read.  bands: n x n_bands samples (nullable). */
 int mis_write_xyz(const char* path, const float* xyz, int n, const float* bands, int n_bands, int append);
 
 /* The three Float32 bands of the reference's disparity GeoTIFF (image3.cpp:853-860, 872-893):

@@ -22,6 +22,16 @@ def test_ncc_golden(ctx, case):
     compare_ncc(gpu, ora, volume=c["volume"], dmin=dmin, check_peak2=True)
 
 
+def test_ncc_golden_u16(ctx):
+    c = load_cases("ncc_cases.npz")["ncc_u16_w15"]
+    win, dmin, dmax = int(c["window"]), int(c["dmin"]), int(c["dmax"])
+    ctx.upload_pair(c["left"], c["right"])
+    gpu = ctx.ncc_dense(win, dmin, dmax)
+    ora = {k: c[k] for k in ("idisp", "disp", "peak")}
+    ora["flat"] = flat_mask(c["volume"], c["idisp"], dmin)
+    compare_ncc(gpu, ora, volume=c["volume"], dmin=dmin)
+
+
 @pytest.mark.parametrize("case", ["xc32", "xc64", "xc128", "impulse", "padded"])
 def test_find_offset_golden(ctx, case):
     c = load_cases("xcorr_cases.npz")[case]

@@ -78,3 +78,51 @@ def test_row_strips_equal_the_full_frame(ctx):
         ctx.ncc_dense_torch(11, -40, 40, part_d, part_p, row0=row0, nrows=n)
     ctx.synchronize()
     assert torch.equal(full_d, part_d) and torch.equal(full_p, part_p)
+
+
+def _texture16(h, w, seed):
+    """16-bit texture using the full range (not just multiples of 257)."""
+    rng = np.random.default_rng(seed)
+    t = synth.texture(h, w, seed, np.uint16).astype(np.int64)
+    t = t + rng.integers(-120, 121, t.shape)
+    return np.clip(t, 0, 65535).astype(np.uint16)
+
+
+@pytest.mark.parametrize("window,dmin,dmax,shape,shift", [
+    (15, -64, 64, (96, 300), 17),
+    (21, -40, 90, (80, 260), -23),
+    (3, -5, 5, (40, 70), 2),
+    (31, -70, 70, (70, 256), 40),
+    (7, 0, 63, (50, 200), 11),
+    (9, -100, 27, (64, 333), -60),
+])
+def test_u16_constant_shift(ctx, window, dmin, dmax, shape, shift):
+    left = _texture16(shape[0], shape[1], 4321 + window)
+    right = synth.shift_right_image(left, shift, fill_seed=98)
+    st = _run(ctx, left, right, window, dmin, dmax)
+    assert st["valid"] > 0
+
+
+def test_u16_extremes(ctx):
+    """Saturated and zero 16-bit regions: the largest products and sums the integer path sees."""
+    rng = np.random.default_rng(11)
+    left = _texture16(80, 300, 6)
+    left[10:50, 60:140] = 65535
+    left[55:, 200:] = 0
+    right = synth.shift_right_image(left, -7, fill_seed=3)
+    right[20:60, 150:260] = (rng.integers(0, 2, (40, 110)) * 65535).astype(np.uint16)
+    _run(ctx, left, right, 31, -40, 40)
+
+
+def test_u16_wide_search_many_chunks(ctx):
+    """17 chunks of 64 disparities (more than one workgroup of the 8-bit v1 kernel could hold)."""
+    left = _texture16(70, 1500, 8)
+    right = synth.shift_right_image(left, 333, fill_seed=4)
+    _run(ctx, left, right, 31, -512, 512)
+
+
+def test_u16_second_peak_is_refused(ctx):
+    left = _texture16(40, 100, 1)
+    ctx.upload_pair(left, left)
+    with pytest.raises(Exception):
+        ctx.ncc_dense(7, -4, 4, want_peak2=True)
