@@ -1,10 +1,10 @@
 // Dense windowed NCC for 16-bit rasters, gfx950: the same lane <-> disparity walk and batched
 // argmax as the 8-bit path (ncc_kernels.hip), with exact 64-bit integer sums instead of the
 // f16/f32 trick: a product of two 16-bit pixels needs 31 bits and a 31x31 window sum 41.
-//   column sums and window sums: int64, updated with v_mad_i64_i32
-//   num = N*S_LR - S_L*S_R exactly (int64), score = float(num) * (1/sqrt(N var_L)) * (1/sqrt(N var_R))
-// Pixels are shifted by 32768 into int16 range first.  Slower than the 8-bit path (quarter-rate
-// 64-bit multiplies), exact like the oracle.  Definition: see mi_stereo.h (dense windowed NCC).
+//   column sums and window sums: binary64, updated with v_fma_f64 (full rate on CDNA3/4); every
+//   value is an integer below 2^53, so the arithmetic is exact
+//   num = N*S_LR - S_L*S_R exactly, score = float(num) * (1/sqrt(N var_L)) * (1/sqrt(N var_R))
+// Pixels are shifted by 32768 into int16 range first.  Exact like the oracle.  Definition: see mi_stereo.h (dense windowed NCC).
 #include "ncc_shared.h"
 
 #include <math.h>
@@ -13,6 +13,7 @@ struct Ncc16Ws {
     int32_t *L32 = nullptr, *R32 = nullptr;     // shifted rasters, pitch P
     int32_t *SL = nullptr, *SR = nullptr;       // window sums of the shifted pixels
     float *iL = nullptr, *iR = nullptr;         // 1/sqrt(N*sum sq - sum^2); iR NaN where the window does not fit
+    double *Ld = nullptr, *SLd = nullptr;       // left pixels and left window sums as binary64 (wave-uniform operands)
     int32_t* hs1 = nullptr; long long* hs2 = nullptr;
     float* keys = nullptr; size_t keys_bytes = 0;
     size_t cap_px = 0;
@@ -24,7 +25,7 @@ void mis_ncc16_release(mis_ctx* ctx)
 {
     Ncc16Ws* w = ctx->ncc16;
     if (!w) return;
-    void* bufs[] = { w->L32, w->R32, w->SL, w->SR, w->iL, w->iR, w->hs1, w->hs2, w->keys };
+    void* bufs[] = { w->L32, w->R32, w->SL, w->SR, w->iL, w->iR, w->hs1, w->hs2, w->keys, w->Ld, w->SLd };
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete w;
     ctx->ncc16 = nullptr;
@@ -32,7 +33,7 @@ void mis_ncc16_release(mis_ctx* ctx)
 
 __global__ __launch_bounds__(256) void ncc16_hsum_kernel(const uint16_t* __restrict__ img, size_t stride_px,
                                                          int W, int H, int r, int pitch, int32_t* __restrict__ p32,
-                                                         int32_t* __restrict__ hs1, long long* __restrict__ hs2)
+                                                         double* __restrict__ pd, int32_t* __restrict__ hs1, long long* __restrict__ hs2)
 {
     __shared__ int tile[256 + 2 * 16];
     const int y = blockIdx.y, x0 = blockIdx.x * 256;
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void ncc16_hsum_kernel(const uint16_t* __restr
     for (int i = 0; i <= 2 * r; i++) { int v = tile[threadIdx.x + i]; s1 += v; s2 += (long long)v * v; }
     const size_t o = (size_t)y * pitch + x;
     p32[o] = tile[threadIdx.x + r];
+    if (pd) pd[o] = (double)tile[threadIdx.x + r];
     hs1[o] = s1; hs2[o] = s2;
 }
 
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void ncc16_hsum_kernel(const uint16_t* __restr
 template <bool LEFT>
 __global__ __launch_bounds__(256) void ncc16_stats_kernel(int W, int H, int r, int pitch,
                                                           const int32_t* __restrict__ hs1, const long long* __restrict__ hs2,
-                                                          int32_t* __restrict__ osum, float* __restrict__ oinv)
+                                                          int32_t* __restrict__ osum, float* __restrict__ oinv, double* __restrict__ osumd)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= pitch) return;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void ncc16_stats_kernel(int W, int H, int r, i
             vs = (int)s1;
             vi = var > 0 ? (float)(1.0 / sqrt((double)var)) : 0.f;
         }
-        if (LEFT) { if (x >= r) { osum[o - r] = vs; oinv[o - r] = vi; } }     // left tables shifted by r (see ncc_kernels.hip)
+        if (LEFT) { if (x >= r) { osum[o - r] = vs; oinv[o - r] = vi; osumd[o - r] = (double)vs; } }     // left tables shifted by r (see ncc_kernels.hip)
         else { osum[o] = vs; oinv[o] = vi; }
     }
 }
@@ -98,13 +100,13 @@ struct Ncc16Cfg {
 // LDS: 4 arrays (entering right row, leaving right row, S_R, 1/sigma_R) x 4 shifted copies.
 template <int R, int WT>
 __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
-    NccArgs a, const int32_t* __restrict__ gL, const int32_t* __restrict__ gR,
-    const int32_t* __restrict__ gSL, const int32_t* __restrict__ gSR, const float* __restrict__ gIR,
+    NccArgs a, const double* __restrict__ gL, const int32_t* __restrict__ gR,
+    const double* __restrict__ gSL, const int32_t* __restrict__ gSR, const float* __restrict__ gIR,
     float* __restrict__ oKeys)
 {
     using Cfg = Ncc16Cfg<R, WT>;
     constexpr int WN = 2 * R + 1, NC = Cfg::NC, NCP = Cfg::NCP, SEG = Cfg::SEG, LENP = Cfg::LENP;
-    constexpr long long NN = (long long)WN * WN;
+    constexpr double NN = (double)(WN * WN);
     __shared__ __attribute__((aligned(16))) int sArr[16 * LENP];
 
     const int lane = threadIdx.x;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
         mycol = (int)ncc_reduce_quads(qi[0], qi[1], qi[2], qi[3], lane);
     }
 
-    long long C[NC];
+    double C[NC];
 #pragma unroll
     for (int k = 0; k < NC; k++) C[k] = 0;
 
@@ -182,10 +184,9 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
 
         const int4* bn4 = (const int4*)(sArr + (0 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
         const int4* bo4 = (const int4*)(sArr + (1 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
-        const int32_t* lnew = gL + (size_t)ynew * P + (x0 - R);
+        const double* lnew = gL + (size_t)ynew * P + (x0 - R);
         const int yold = ynew - WN;
-        const int32_t* lold = gL + (size_t)(yold >= 0 ? yold : 0) * P + (x0 - R);
-        const bool use_old = !warm && yold >= 0;
+        const double* lold = gL + (size_t)(yold >= 0 ? yold : 0) * P + (x0 - R);
 #pragma unroll
         for (int kb = 0; kb < NCP / 4; kb++) {
             const int4 bn = bn4[kb], bo = bo4[kb];
@@ -194,19 +195,20 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
             for (int e = 0; e < 4; e++) {
                 const int k = 4 * kb + e;
                 if (k < NC) {
-                    const int an = lnew[k];
-                    const int ao = use_old ? -lold[k] : 0;
-                    C[k] += (long long)an * bnv[e];
-                    C[k] += (long long)ao * bov[e];
+                    const double an = lnew[k];
+                    const double ao = -lold[k];            // its partner bo is staged as 0 while the window fills
+                    C[k] = __builtin_fma(an, (double)bnv[e], C[k]);
+                    C[k] = __builtin_fma(ao, (double)bov[e], C[k]);
                 }
             }
+            if ((kb & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // keeps the scalar loads of later columns from piling up
         }
 
         if (score) {
             const int4* sr4 = (const int4*)(sArr + (2 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
             const float4* ir4 = (const float4*)(sArr + (3 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
-            const int32_t* slrow = gSL + (size_t)yout * P + (x0 - R);
-            long long S = 0;
+            const double* slrow = gSL + (size_t)yout * P + (x0 - R);
+            double S = 0.0;
 #pragma unroll
             for (int k = 0; k < 2 * R; k++) S += C[k];
             float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
                 for (int e = 0; e < 4; e++) {
                     const int j = 4 * g + e;
                     S += C[j + 2 * R];
-                    const long long num = NN * S - (long long)slrow[j] * (long long)srv[e];   // exact
+                    const double num = __builtin_fma(NN, S, -(slrow[j] * (double)srv[e]));   // exact: integers below 2^53
                     const float sc = __builtin_fmaf((float)num, irv[e], bias);
                     S -= C[j];
                     tr.push(j & 15, ncc_make_key(sc, tag));
@@ -261,24 +263,27 @@ __global__ __launch_bounds__(256) void ncc16_refine_kernel(
     if (oIdisp) oIdisp[o] = (int16_t)ds;
     if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; return; }
     const int u = x - ds;
-    long long Sm = 0, S0 = 0, Sp = 0;            // disparities ds-1, ds, ds+1 <-> right columns u+1, u, u-1
+    double Sm = 0.0, S0 = 0.0, Sp = 0.0;         // disparities ds-1, ds, ds+1 <-> right columns u+1, u, u-1
     for (int j = -R; j <= R; j++) {
         const int32_t* lr = gL + (size_t)(y + j) * P;
         const int32_t* rr = gR + (size_t)(y + j) * P;
+        double rb = (double)rr[min(max(u - R, 0), P - 1)], rc = (double)rr[min(max(u - R - 1, 0), P - 1)];
+#pragma unroll 4
         for (int i = -R; i <= R; i++) {
-            const long long l = lr[x + i];
-            const int c0 = u + i;
-            Sm += l * rr[min(max(c0 + 1, 0), P - 1)];
-            S0 += l * rr[min(max(c0, 0), P - 1)];
-            Sp += l * rr[min(max(c0 - 1, 0), P - 1)];
+            const double l = (double)lr[x + i];
+            const double ra = (double)rr[min(max(u + i + 1, 0), P - 1)];
+            Sm = __builtin_fma(l, ra, Sm);
+            S0 = __builtin_fma(l, rb, S0);
+            Sp = __builtin_fma(l, rc, Sp);
+            rc = rb; rb = ra;
         }
     }
-    constexpr long long NN = (long long)(2 * R + 1) * (2 * R + 1);
-    const long long sl = gSL[(size_t)y * P + (x - R)];
+    constexpr double NN = (double)((2 * R + 1) * (2 * R + 1));
+    const double sl = (double)gSL[(size_t)y * P + (x - R)];
     const float il = gIL[(size_t)y * P + (x - R)];
-    auto score = [&](long long S, int col, int d) -> float {
+    auto score = [&](double S, int col, int d) -> float {
         if (d < a.dmin || d > a.dmax || col < 0 || col >= a.W) return __builtin_nanf("");
-        const long long num = NN * S - sl * (long long)gSR[(size_t)y * P + col];
+        const double num = __builtin_fma(NN, S, -(sl * (double)gSR[(size_t)y * P + col]));
         return __builtin_fmaf((float)num, gIR[(size_t)y * P + col], 0.f);
     };
     const float sm = score(Sm, u + 1, ds - 1), s0 = score(S0, u, ds), sp = score(Sp, u - 1, ds + 1);
@@ -302,10 +307,11 @@ static int ncc16_prepare(mis_ctx* ctx, int window)
         void** b4[] = { (void**)&w->L32, (void**)&w->R32, (void**)&w->SL, (void**)&w->SR, (void**)&w->iL, (void**)&w->iR,
                         (void**)&w->hs1 };
         for (void** b : b4) { if (*b) { MIS_HIP(ctx, hipFree(*b)); *b = nullptr; } }
-        if (w->hs2) { MIS_HIP(ctx, hipFree(w->hs2)); w->hs2 = nullptr; }
+        void** b8[] = { (void**)&w->hs2, (void**)&w->Ld, (void**)&w->SLd };
+        for (void** b : b8) { if (*b) { MIS_HIP(ctx, hipFree(*b)); *b = nullptr; } }
         w->cap_px = 0;
         for (void** b : b4) MIS_HIP(ctx, hipMalloc(b, npx * 4));
-        MIS_HIP(ctx, hipMalloc((void**)&w->hs2, npx * 8));
+        for (void** b : b8) MIS_HIP(ctx, hipMalloc(b, npx * 8));
         w->cap_px = npx;
         w->pair_serial = 0;
     }
@@ -315,10 +321,10 @@ static int ncc16_prepare(mis_ctx* ctx, int window)
     dim3 sgrid((pitch + 255) / 256, (H + NCC16_STATS_BAND - 1) / NCC16_STATS_BAND);
     hipStream_t s = ctx->stream;
     const size_t stride_px = ctx->stride / 2;
-    hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[0], stride_px, W, H, r, pitch, w->L32, w->hs1, w->hs2);
-    hipLaunchKernelGGL(ncc16_stats_kernel<true>, sgrid, block, 0, s, W, H, r, pitch, w->hs1, w->hs2, w->SL, w->iL);
-    hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[1], stride_px, W, H, r, pitch, w->R32, w->hs1, w->hs2);
-    hipLaunchKernelGGL(ncc16_stats_kernel<false>, sgrid, block, 0, s, W, H, r, pitch, w->hs1, w->hs2, w->SR, w->iR);
+    hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[0], stride_px, W, H, r, pitch, w->L32, w->Ld, w->hs1, w->hs2);
+    hipLaunchKernelGGL(ncc16_stats_kernel<true>, sgrid, block, 0, s, W, H, r, pitch, w->hs1, w->hs2, w->SL, w->iL, w->SLd);
+    hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[1], stride_px, W, H, r, pitch, w->R32, (double*)nullptr, w->hs1, w->hs2);
+    hipLaunchKernelGGL(ncc16_stats_kernel<false>, sgrid, block, 0, s, W, H, r, pitch, w->hs1, w->hs2, w->SR, w->iR, (double*)nullptr);
     MIS_HIP(ctx, hipGetLastError());
     w->pair_serial = ctx->pair_serial;
     w->window = window;
@@ -335,7 +341,7 @@ static int ncc16_launch(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, i
     a.nstrips = (a.W - 2 * R + WT - 1) / WT;
     a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
     hipLaunchKernelGGL((ncc16_argmax_kernel<R, WT>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
-                       a, w->L32, w->R32, w->SL, w->SR, w->iR, w->keys);
+                       a, w->Ld, w->R32, w->SLd, w->SR, w->iR, w->keys);
     mis_prof_mark(ctx);
     hipLaunchKernelGGL(ncc16_refine_kernel<R>, dim3((a.W - 2 * R + 255) / 256, a.row1 - a.row0), dim3(256), 0, ctx->stream,
                        a, w->L32, w->R32, w->SL, w->iL, w->SR, w->iR, w->keys, a.nchunk, d_disp, d_peak, d_idisp);
