@@ -700,73 +700,96 @@ __global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
 
 // Refinement: exact window correlation of the winner and its two neighbours from vertically packed
 // int8 pixels (v_dot4_i32_i8: four rows per instruction), then the same float expression as the
-// argmax kernel, the parabola vertex and the outputs.  One thread per pixel, 256 pixels of one row
-// per workgroup.
+// argmax kernel, the parabola vertex and the outputs.
+// One workgroup = NCC_REF_BW consecutive pixels of 4 consecutive rows (512 threads, a wavefront is
+// 64 pixels of one row).  Neighbouring pixels need not agree on their disparity (occlusions,
+// mismatches), so per-pixel gathers from global memory would touch whole cache lines for a few
+// bytes each; instead the workgroup stages, once, every quad row its windows touch: the left
+// columns of the run and the right columns of the run for the WHOLE search range, and each pixel
+// then reads its 2R+1 left and 2R+3 right columns from LDS.
+#define NCC_REF_BW 128
 template <int R>
-__global__ __launch_bounds__(256) void ncc_refine_kernel(
+struct NccRefineCfg {
+    static constexpr int NQ = (2 * R + 7) / 4 + 1;       // quad rows the windows of 4 consecutive rows can touch
+    static constexpr int LC = NCC_REF_BW + 2 * R;        // left columns of the run
+    static int right_cols(int nd) { return NCC_REF_BW + (nd - 1) + 2 * R + 3; }
+    static size_t lds_bytes(int nd) { return (size_t)NQ * (LC + right_cols(nd)) * sizeof(uint32_t); }
+};
+
+template <int R>
+__global__ __launch_bounds__(512) void ncc_refine_kernel(
     NccArgs a, const uint32_t* __restrict__ VL, const uint32_t* __restrict__ VR,
     const float* __restrict__ gNegc, const float* __restrict__ gNegg, const float* __restrict__ gIL,
     const float* __restrict__ gRsr, const float* __restrict__ gRir, const float* __restrict__ gKeys, int nchunk,
     float* __restrict__ oDisp, float* __restrict__ oPeak, int16_t* __restrict__ oIdisp)
 {
-    constexpr int NQ = (2 * R + 3) / 4 + 1;      // quads of 4 rows a (2R+1)-row window can touch
-    const int x = R + blockIdx.x * 256 + threadIdx.x;
-    const int y = a.row0 + blockIdx.y;
-    if (x >= a.W - R) return;
+    using Cfg = NccRefineCfg<R>;
+    constexpr int NQ = Cfg::NQ, LC = Cfg::LC;
+    extern __shared__ uint32_t ncc_refine_lds[];
+    const int NC = NCC_REF_BW + (a.dmax - a.dmin) + 2 * R + 3;     // == Cfg::right_cols(nd)
+    uint32_t* tL = ncc_refine_lds;               // [NQ][LC]
+    uint32_t* tR = ncc_refine_lds + NQ * LC;     // [NQ][NC]
+
+    const int tid = threadIdx.x;
+    const int lx = tid & (NCC_REF_BW - 1), ly = tid / NCC_REF_BW;
+    const int x0 = R + blockIdx.x * NCC_REF_BW;
+    const int y0 = a.row0 + 4 * blockIdx.y;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool inside = (x < a.W - R) && (y < a.row1);
     const int P = a.pitch;
     const size_t o = (size_t)y * a.out_pitch + x;
     // merge the chunk keys: lowest chunk wins among equal (truncated) scores
     int ds = MIS_INVALID_DISP;
-    {
+    if (inside) {
         float best = -1.0e30f;                     // below any score, above the bias of masked lanes
         for (int c = 0; c < nchunk; c++) {
             const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * a.H * a.out_pitch + o]);
             const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
             if (v > best) { best = v; ds = a.dmin + c * 64 + 63 - (int)(kb & 63u); }
         }
+        if (oIdisp) oIdisp[o] = (int16_t)ds;
+        if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; }
     }
-    if (oIdisp) oIdisp[o] = (int16_t)ds;
-    if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; return; }
+    const bool valid = inside && ds != MIS_INVALID_DISP;
 
-    const int q0 = (y - R) >> 2;
-    uint32_t mask[NQ];
+    const int qb = (y0 - R) >> 2;                 // first staged quad row
+    const int nq_rows = (a.H + 3) >> 2;
+    const int cbase = x0 - a.dmax - R - 1;        // raster column of right-tile column 0
+    for (int qi = 0; qi < NQ; qi++) {
+        const int q = min(qb + qi, nq_rows - 1);
+        const uint32_t* lrow = VL + (size_t)q * P + (x0 - R);
+        const uint32_t* rrow = VR + (size_t)q * P;
+        for (int c = tid; c < LC; c += 512) tL[qi * LC + c] = lrow[c];
+        for (int c = tid; c < NC; c += 512) tR[qi * NC + c] = rrow[min(max(cbase + c, 0), P - 1)];
+    }
+    __syncthreads();
+    if (!valid) return;
+
+    const int u = x - ds;                         // window centre in the right image for the winner
+    int Sm = 0, S0 = 0, Sp = 0;                   // disparities ds-1, ds, ds+1 <-> columns u+1, u, u-1
+    const uint32_t* pl = tL + lx;                            // column x-R
+    const uint32_t* pr = tR + (u - R - 1 - cbase);           // column u-R-1
 #pragma unroll
     for (int qi = 0; qi < NQ; qi++) {
         uint32_t m = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int row = 4 * (q0 + qi) + k;
+            const int row = 4 * (qb + qi) + k;
             if (row >= y - R && row <= y + R) m |= 0xFFu << (8 * k);
         }
-        mask[qi] = m;
-    }
-    const int nq_rows = (a.H + 3) >> 2;
-    const int u = x - ds;                         // window centre in the right image for the winner
-    int Sm = 0, S0 = 0, Sp = 0;                   // disparities ds-1, ds, ds+1 <-> columns u+1, u, u-1
-    uint32_t ra[NQ], rb[NQ], rc[NQ];              // right columns u+i+1, u+i, u+i-1
-    auto loadR = [&](uint32_t (&dst)[NQ], int col) {
-        col = min(max(col, 0), P - 1);
+        if (m == 0) continue;                     // wave-uniform: a wavefront is one row
+        const uint32_t* plq = pl + qi * LC;
+        const uint32_t* prq = pr + qi * NC;
+        uint32_t rc = prq[0], rb = prq[1];
 #pragma unroll
-        for (int qi = 0; qi < NQ; qi++) {
-            const int q = min(q0 + qi, nq_rows - 1);
-            dst[qi] = VR[(size_t)q * P + col];
+        for (int i = 0; i <= 2 * R; i++) {
+            const uint32_t ra = prq[i + 2];
+            const uint32_t l = plq[i] & m;
+            Sm = __builtin_amdgcn_sdot4((int)l, (int)ra, Sm, false);
+            S0 = __builtin_amdgcn_sdot4((int)l, (int)rb, S0, false);
+            Sp = __builtin_amdgcn_sdot4((int)l, (int)rc, Sp, false);
+            rc = rb; rb = ra;
         }
-    };
-    loadR(rb, u - R);
-    loadR(rc, u - R - 1);
-#pragma unroll 1
-    for (int i = -R; i <= R; i++) {
-        loadR(ra, u + i + 1);
-#pragma unroll
-        for (int qi = 0; qi < NQ; qi++) {
-            const int q = min(q0 + qi, nq_rows - 1);
-            const uint32_t l = VL[(size_t)q * P + x + i] & mask[qi];
-            Sm = __builtin_amdgcn_sdot4((int)l, (int)ra[qi], Sm, false);
-            S0 = __builtin_amdgcn_sdot4((int)l, (int)rb[qi], S0, false);
-            Sp = __builtin_amdgcn_sdot4((int)l, (int)rc[qi], Sp, false);
-        }
-#pragma unroll
-        for (int qi = 0; qi < NQ; qi++) { rc[qi] = rb[qi]; rb[qi] = ra[qi]; }
     }
 
     const float nc = gNegc[(size_t)y * P + (x - R)], ng = gNegg[(size_t)y * P + (x - R)], il = gIL[(size_t)y * P + (x - R)];
@@ -885,8 +908,14 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     hipLaunchKernelGGL((ncc_argmax_kernel<R, WT>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
                        a, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
     mis_prof_mark(ctx);
-    hipLaunchKernelGGL(ncc_refine_kernel<R>, dim3((a.W - 2 * R + 255) / 256, a.row1 - a.row0), dim3(256), 0, ctx->stream,
-                       a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, a.nchunk, d_disp, d_peak, d_idisp);
+    {
+        const size_t lds = NccRefineCfg<R>::lds_bytes(a.dmax - a.dmin + 1);
+        if (lds > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ncc_refine_kernel<R>, dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
+                           lds, ctx->stream,
+                           a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, a.nchunk, d_disp, d_peak, d_idisp);
+    }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
