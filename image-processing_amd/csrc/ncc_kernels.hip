@@ -476,6 +476,7 @@ __global__ __launch_bounds__(1024) void ncc_main_kernel(
 __device__ __forceinline__ void ncc_pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void ncc_pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
 __device__ __forceinline__ void ncc_pin_s(float& v) { asm volatile("" : "+s"(v)); }
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 // Argmax kernel: ONE wavefront per workgroup = one chunk of 64 disparities for one strip of WT
 // columns and one band of rows; wavefronts never synchronise with each other.
@@ -491,8 +492,8 @@ struct NccWaveCfg {
     static constexpr int LENP = ((SEG + 3 + 47) / 64) * 64 + 16;   // >= SEG + 3, == 16 (mod 64)
 };
 
-template <int R, int WT>
-__global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
+template <int R, int WT, int MW>
+__global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
     NccArgs a,
     const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
     const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr, const float* __restrict__ gRir,
@@ -502,6 +503,7 @@ __global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
     using Cfg = NccWaveCfg<R, WT>;
     constexpr int WN = 2 * R + 1;
     constexpr int NCP = Cfg::NCP, SEG = Cfg::SEG, LENP = Cfg::LENP;
+    constexpr int GA = MW >= 5 ? 8 : 16, GB = MW >= 5 ? 4 : 8;      // columns per software-pipeline stage
     __shared__ __attribute__((aligned(16))) float sArr[12 * LENP];   // [3 arrays][4 copies][LENP]
 
     const int lane = threadIdx.x;
@@ -534,6 +536,7 @@ __global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
     // pattern once the lane tag is inserted, and v_max_f32 propagates signalling NaNs
     const float bias = (d <= a.dmax) ? 0.f : -3.0e38f;
     const uint32_t tag = 63u - (uint32_t)lane;
+    const float2_t bias2 = { bias, bias };
 
     const int cA = loff & 3;
     const int offB = loff + R, cB = offB & 3;
@@ -558,10 +561,11 @@ __global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
     const int P = a.pitch;
 
     // right-image row -> LDS (this wavefront's columns only); element i <-> raster column xr0 + i
-    uint32_t nbp[3]; float nsr[3], nir[3];
+    constexpr int NSTG = (SEG + 63) / 64;      // staged elements per lane
+    uint32_t nbp[NSTG]; float nsr[NSTG], nir[NSTG];
     auto fetch = [&](int ynew, int yout, bool stats, bool warm) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
+        for (int q = 0; q < NSTG; q++) {
             const int i = lane + 64 * q;
             const int xr = xr0 + i;
             const bool in = (xr >= 0 && xr < a.W && i < SEG);
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
     };
     auto publish = [&](bool stats) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
+        for (int q = 0; q < NSTG; q++) {
             const int i = lane + 64 * q;
             if (i < SEG) {
 #pragma unroll
@@ -604,20 +608,20 @@ __global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
         {
             const float4* bp4 = (const float4*)(sArr + (0 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
             const uint32_t* lrow = gLpack + (size_t)ynew * P + (x0 - R);
-            constexpr int NGA = (NCP + 15) / 16;
-            float bv[2][16];
-            uint32_t av[2][16];
+            constexpr int NGA = (NCP + GA - 1) / GA;
+            float bv[2][GA];
+            uint32_t av[2][GA];
             auto loadA = [&](int g, int set) {
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    if (16 * g + 4 * v < NCP) {
-                        const float4 f = bp4[4 * g + v];
+                for (int v = 0; v < GA / 4; v++) {
+                    if (GA * g + 4 * v < NCP) {
+                        const float4 f = bp4[(GA / 4) * g + v];
                         bv[set][4 * v] = f.x; bv[set][4 * v + 1] = f.y; bv[set][4 * v + 2] = f.z; bv[set][4 * v + 3] = f.w;
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 16; e++)
-                    if (16 * g + e < NCP) av[set][e] = lrow[16 * g + e];
+                for (int e = 0; e < GA; e++)
+                    if (GA * g + e < NCP) av[set][e] = lrow[GA * g + e];
             };
             loadA(0, 0);
 #pragma unroll
@@ -627,8 +631,8 @@ __global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
                 if (g + 1 < NGA) loadA(g + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int k = 16 * g + e;
+                for (int e = 0; e < GA; e++) {
+                    const int k = GA * g + e;
                     if (k < NCP) {
                         ncc_pin(bv[set][e]);
                         ncc_pin_s(av[set][e]);
@@ -650,17 +654,17 @@ __global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
 #pragma unroll
             for (int k = 0; k < 2 * R; k++) S += C[k];
             float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
-            constexpr int NGB = WT / 8;
-            float sv[2][8], iv[2][8], cv[2][8], gv[2][8];
+            constexpr int NGB = WT / GB;
+            float sv[2][GB], iv[2][GB], cv[2][GB], gv[2][GB];
             auto loadB = [&](int g, int set) {
 #pragma unroll
-                for (int v = 0; v < 2; v++) {
-                    const float4 f = sr4[2 * g + v], h = ir4[2 * g + v];
+                for (int v = 0; v < GB / 4; v++) {
+                    const float4 f = sr4[(GB / 4) * g + v], h = ir4[(GB / 4) * g + v];
                     sv[set][4 * v] = f.x; sv[set][4 * v + 1] = f.y; sv[set][4 * v + 2] = f.z; sv[set][4 * v + 3] = f.w;
                     iv[set][4 * v] = h.x; iv[set][4 * v + 1] = h.y; iv[set][4 * v + 2] = h.z; iv[set][4 * v + 3] = h.w;
                 }
 #pragma unroll
-                for (int e = 0; e < 8; e++) { cv[set][e] = ncrow[8 * g + e]; gv[set][e] = ngrow[8 * g + e]; }
+                for (int e = 0; e < GB; e++) { cv[set][e] = ncrow[GB * g + e]; gv[set][e] = ngrow[GB * g + e]; }
             };
             loadB(0, 0);
             NccTree tr;
@@ -671,18 +675,28 @@ __global__ __launch_bounds__(64, 3) void ncc_argmax_kernel(
                 if (g + 1 < NGB) loadB(g + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int j = 8 * g + e;
-                    ncc_pin(sv[set][e]); ncc_pin(iv[set][e]);
-                    ncc_pin_s(cv[set][e]); ncc_pin_s(gv[set][e]);
-                    S += C[j + 2 * R];
-                    const float tt = __builtin_fmaf(cv[set][e], sv[set][e], S);     // S - c*S_R, exact
-                    const float cov = __builtin_fmaf(gv[set][e], sv[set][e], tt);   // - (rem/N)*S_R
-                    const float sc = __builtin_fmaf(cov, iv[set][e], bias);
-                    S -= C[j];
-                    tr.push(j & 15, __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, sc) & 0xFFFFFFC0u) | tag));
+                for (int e = 0; e < GB; e += 2) {
+                    const int j = GB * g + e;
+                    // two columns per packed fma (v_pk_fma_f32)
+                    ncc_pin(sv[set][e]); ncc_pin(sv[set][e + 1]); ncc_pin(iv[set][e]); ncc_pin(iv[set][e + 1]);
+                    ncc_pin_s(cv[set][e]); ncc_pin_s(cv[set][e + 1]); ncc_pin_s(gv[set][e]); ncc_pin_s(gv[set][e + 1]);
+                    const float2_t s2 = { sv[set][e], sv[set][e + 1] }, i2 = { iv[set][e], iv[set][e + 1] };
+                    const float2_t c2 = { cv[set][e], cv[set][e + 1] }, g2 = { gv[set][e], gv[set][e + 1] };
+                    const float Sa = S + C[j + 2 * R];
+                    const float Sb = (Sa - C[j]) + C[j + 1 + 2 * R];
+                    S = Sb - C[j + 1];
+                    const float2_t S2 = { Sa, Sb };
+                    const float2_t tt = __builtin_elementwise_fma(c2, s2, S2);       // S - c*S_R, exact
+                    const float2_t cov = __builtin_elementwise_fma(g2, s2, tt);      // - (rem/N)*S_R
+                    const float2_t sc = __builtin_elementwise_fma(cov, i2, bias2);
+                    // the two halves go through pins: this compiler otherwise merges the two key
+                    // computations into one and uses the first column's key for both
+                    float sca = sc.x, scb = sc.y;
+                    ncc_pin(sca); ncc_pin(scb);
+                    tr.push(j & 15, ncc_make_key(sca, tag));
+                    tr.push((j + 1) & 15, ncc_make_key(scb, tag));
                 }
-                if ((g & 1) == 1) q[g >> 1] = tr.q;
+                if (((GB * (g + 1)) & 15) == 0) q[(GB * g) >> 4] = tr.q;
                 ncc_pin(S);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -896,7 +910,7 @@ static int ncc_launch(mis_ctx* ctx, const NccArgs& a, float* d_disp, float* d_pe
     return MIS_OK;
 }
 
-template <int R, int WT>
+template <int R, int WT, int MW>
 static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
 {
     NccWs* w = ctx->ncc;
@@ -905,7 +919,7 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     if (rc) return rc;
     a.nstrips = (a.W - 2 * R + WT - 1) / WT;
     a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
-    hipLaunchKernelGGL((ncc_argmax_kernel<R, WT>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
+    hipLaunchKernelGGL((ncc_argmax_kernel<R, WT, MW>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
                        a, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
     mis_prof_mark(ctx);
     {
@@ -978,8 +992,10 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     if (total_chunks > 16 && d_peak2)
         return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: the second-peak output supports at most 1024 disparities");
     a.nchunk = total_chunks;
+#define NCC_WT(RR) 32
+#define NCC_MW(RR) ((RR) <= 11 ? 5 : 3)
 #define NCC_CASE(RR) case RR: rc = d_peak2 ? ncc_launch<RR, 32>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
-                               : ncc_launch_fast<RR, (RR <= 11 ? 64 : 32)>(ctx, a, d_disp, d_peak, d_idisp); break;
+                               : ncc_launch_fast<RR, NCC_WT(RR), NCC_MW(RR)>(ctx, a, d_disp, d_peak, d_idisp); break;
     switch (r) {
         NCC_CASE(1) NCC_CASE(2) NCC_CASE(3) NCC_CASE(4) NCC_CASE(5) NCC_CASE(6) NCC_CASE(7) NCC_CASE(8)
         NCC_CASE(9) NCC_CASE(10) NCC_CASE(11) NCC_CASE(12) NCC_CASE(13) NCC_CASE(14) NCC_CASE(15)
