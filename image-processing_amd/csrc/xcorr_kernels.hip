@@ -17,6 +17,7 @@
 #include <math.h>
 #include <string.h>
 #include <map>
+#include <utility>
 #include <vector>
 
 #define XC_GAUSS_K 151          // cv::Size(151,151) at image3.cpp:481
@@ -25,6 +26,7 @@
 
 struct XcorrWs {
     std::map<int, float2*> twiddle;     // per FFT length n: n/2 values exp(-2 pi i k / n)
+    std::map<int, float2*> chirp;       // per non-power-of-two length n: n chirp values, then the M filter values
     float* gauss = nullptr;             // 151 taps
     void* buf = nullptr; size_t buf_bytes = 0;      // spectra / surfaces of one batch of tiles
     void* meta = nullptr; size_t meta_bytes = 0;    // per-tile min/max, argmax keys, rects
@@ -35,6 +37,7 @@ void mis_xcorr_release(mis_ctx* ctx)
     XcorrWs* w = ctx->xc;
     if (!w) return;
     for (auto& kv : w->twiddle) (void)hipFree(kv.second);
+    for (auto& kv : w->chirp) (void)hipFree(kv.second);
     if (w->gauss) (void)hipFree(w->gauss);
     if (w->buf) (void)hipFree(w->buf);
     if (w->meta) (void)hipFree(w->meta);
@@ -408,15 +411,230 @@ __global__ void xc_init_meta(int n, unsigned* minmax, unsigned long long* keys)
 }
 
 // ---------------------------------------------------------------------------------------------
+// General sizes (the first level of image3.cpp's recursion correlates the two whole rasters, whose
+// sides are whatever the photographs are; FFTW takes any length, image3.cpp:365-372).
+// A 1-D DFT of a length n that is not a power of two is computed as a chirp-z (Bluestein)
+// convolution of length M = 2^k >= 2n-1 in LDS:
+//     X[k] = c[k] * sum_j (x[j] c[j]) conj(c[k-j]),   c[j] = exp(-i pi j^2 / n)
+// with the transform of the conj(c) filter precomputed in double (stored in the bit-reversed order
+// the DIF transform produces).  The 2-D transform is rows, transpose, rows, so that every 1-D
+// transform reads a contiguous sequence.  Slower than the power-of-two path (two transposes, natural
+// order throughout); it runs once per pair.
+// ---------------------------------------------------------------------------------------------
+struct XgDft { int n, M, logM, pow2; const float2* chirp; const float2* filt; const float2* tw; };
+
+// In-place DFT of sequences of length d.n.  Sequence r lives at data + (r / per_batch) * batch_stride
+// + (r % per_batch) * n.  inverse != 0: unnormalised backward transform (conjugate, forward, conjugate).
+__global__ __launch_bounds__(512) void xg_dft_rows(float2* __restrict__ data, XgDft d, int per_batch,
+                                                   size_t batch_stride, int inverse)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* x = (float2*)smem_raw;
+    const int r = blockIdx.x;
+    float2* row = data + (size_t)(r / per_batch) * batch_stride + (size_t)(r % per_batch) * d.n;
+    const float sgn = inverse ? -1.f : 1.f;
+    if (d.pow2) {
+        for (int i = threadIdx.x; i < d.n; i += blockDim.x) { float2 v = row[i]; v.y *= sgn; x[i] = v; }
+        __syncthreads();
+        fft_dif_fwd(x, d.logM, 1, d.tw);
+        for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+            float2 v = x[i]; v.y *= sgn;
+            row[d.logM ? bitrev(i, d.logM) : 0] = v;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < d.M; i += blockDim.x) {
+        float2 v = make_float2(0.f, 0.f);
+        if (i < d.n) { v = row[i]; v.y *= sgn; v = cmul(v, d.chirp[i]); }
+        x[i] = v;
+    }
+    __syncthreads();
+    fft_dif_fwd(x, d.logM, 1, d.tw);
+    for (int i = threadIdx.x; i < d.M; i += blockDim.x) x[i] = cmul(x[i], d.filt[i]);
+    __syncthreads();
+    fft_dit_inv(x, d.logM, 1, d.tw);
+    const float inv_m = 1.0f / (float)d.M;
+    for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+        float2 v = cmul(x[i], d.chirp[i]);
+        row[i] = make_float2(v.x * inv_m, sgn * v.y * inv_m);
+    }
+}
+
+// out[b][c][r] = in[b][r][c]; grid (ceil(cols/32), ceil(rows/32), batches), 256 threads
+__global__ __launch_bounds__(256) void xg_transpose(const float2* __restrict__ in, float2* __restrict__ out,
+                                                    int rows, int cols, size_t in_stride, size_t out_stride)
+{
+    __shared__ float2 tile[32][33];
+    const float2* src = in + (size_t)blockIdx.z * in_stride;
+    float2* dst = out + (size_t)blockIdx.z * out_stride;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = src[(size_t)(r0 + j) * cols + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < cols && r0 + tx < rows) dst[(size_t)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
+// tiles of both images as complex rasters, zero outside the bounding box (image3.cpp:322-328)
+__global__ __launch_bounds__(256) void xg_load_tiles(XcImage im, const mis_rect* __restrict__ r1,
+                                                     const mis_rect* __restrict__ r2, int tile0, int w, int h,
+                                                     float2* __restrict__ spec)
+{
+    const int t = blockIdx.z >> 1, side = blockIdx.z & 1, ry = blockIdx.y;
+    const int rx = blockIdx.x * 256 + threadIdx.x;
+    if (rx >= w) return;
+    const mis_rect bb = side ? r2[tile0 + t] : r1[tile0 + t];
+    float v = 0.f;
+    if (rx < bb.width && ry < bb.height) {
+        const int sx = bb.minx + rx, sy = bb.miny + ry;
+        if (sx >= 0 && sx < im.iw && sy >= 0 && sy < im.ih) v = load_px(im.img[side], im.dtype, im.stride, sx, sy);
+    }
+    spec[((size_t)blockIdx.z * h + ry) * w + rx] = make_float2(v, 0.f);
+}
+
+// a <- (a s)(conj(b s)) for the two spectra of every tile (image3.cpp:331-334, 392-394)
+__global__ __launch_bounds__(256) void xg_product(float2* __restrict__ spec, size_t N, float scale)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float2* sa = spec + (size_t)blockIdx.y * 2 * N;
+    float2 a = sa[i], b = sa[N + i];
+    a.x *= scale; a.y *= scale; b.x *= scale; b.y *= scale;
+    sa[i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+
+// |c| / sqrt(N) and the tile extrema (image3.cpp:401-411), as in xc_rows_inv_abs
+__global__ __launch_bounds__(256) void xg_abs_minmax(const float2* __restrict__ spec, size_t N, float scale,
+                                                     float* __restrict__ surf, unsigned* __restrict__ minmax)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    float lo = INFINITY, hi = 0.f;
+    if (i < N) {
+        const float2 v = spec[(size_t)t * 2 * N + i];
+        const float m = (float)hypot((double)(v.x * scale), (double)(v.y * scale));
+        surf[(size_t)t * N + i] = m;
+        lo = hi = m;
+    }
+    lo = wave_min_f(lo); hi = wave_max_f(hi);
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+        atomicMin(&minmax[2 * t], __float_as_uint(lo));
+        atomicMax(&minmax[2 * t + 1], __float_as_uint(hi));
+    }
+}
+
+// raster of any pixel type -> complex (image-fft.cpp:66-71)
+__global__ __launch_bounds__(256) void xg_load_raster(const void* __restrict__ in, int dtype, size_t n,
+                                                      float2* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v;
+    if (dtype == MIS_U8) v = (float)((const uint8_t*)in)[i];
+    else if (dtype == MIS_U16) v = (float)((const uint16_t*)in)[i];
+    else v = ((const float*)in)[i];
+    out[i] = make_float2(v, 0.f);
+}
+
+// division by sqrt(N) held in double (image-fft.cpp:84-87)
+__global__ __launch_bounds__(256) void xg_divide(float2* __restrict__ x, size_t n, double norm)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 v = x[i];
+    x[i] = make_float2((float)((double)v.x / norm), (float)((double)v.y / norm));
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
-struct XcPlan { int w, h, logw, logh, RBw, CB; };
+struct XcPlan { int w, h, logw, logh, RBw, CB; bool general; };
+
+// descriptor of a 1-D DFT of any length 1..16384 (powers of two) or 1..8192 (other lengths)
+static int get_dft(mis_ctx* ctx, int n, XgDft* d)
+{
+    XcorrWs* w = ctx->xc;
+    d->n = n; d->chirp = nullptr; d->filt = nullptr;
+    if (is_pow2(n)) {
+        d->pow2 = 1; d->M = n; d->logM = ilog2(n);
+        return get_twiddle(ctx, n, &d->tw);
+    }
+    d->pow2 = 0;
+    d->M = 1; while (d->M < 2 * n - 1) d->M <<= 1;
+    d->logM = ilog2(d->M);
+    int rc = get_twiddle(ctx, d->M, &d->tw); if (rc) return rc;
+    auto it = w->chirp.find(n);
+    if (it == w->chirp.end()) {
+        const int M = d->M, logM = d->logM;
+        std::vector<double> cr(n), ci(n), fr(M, 0.0), fi(M, 0.0);
+        for (int j = 0; j < n; j++) {
+            const long long q = ((long long)j * j) % (2LL * n);          // j^2 mod 2n keeps the angle small
+            const double a = -M_PI * (double)q / (double)n;
+            cr[j] = cos(a); ci[j] = sin(a);
+        }
+        for (int j = 0; j < n; j++) {                                     // filter conj(c), wrapped
+            fr[j] = cr[j]; fi[j] = -ci[j];
+            if (j) { fr[M - j] = cr[j]; fi[M - j] = -ci[j]; }
+        }
+        // forward transform of the filter in double: iterative radix-2, natural order out
+        for (int i = 0, j = 0; i < M; i++) {
+            if (i < j) { std::swap(fr[i], fr[j]); std::swap(fi[i], fi[j]); }
+            int m = M >> 1;
+            while (m >= 1 && (j & m)) { j ^= m; m >>= 1; }
+            j |= m;
+        }
+        for (int len = 2; len <= M; len <<= 1) {
+            const double ang = -2.0 * M_PI / (double)len;
+            for (int i = 0; i < M; i += len)
+                for (int k = 0; k < len / 2; k++) {
+                    const double wr = cos(ang * k), wi = sin(ang * k);
+                    const int a0 = i + k, a1 = a0 + len / 2;
+                    const double tr = fr[a1] * wr - fi[a1] * wi, ti = fr[a1] * wi + fi[a1] * wr;
+                    fr[a1] = fr[a0] - tr; fi[a1] = fi[a0] - ti;
+                    fr[a0] += tr; fi[a0] += ti;
+                }
+        }
+        std::vector<float2> hbuf((size_t)n + M);
+        for (int j = 0; j < n; j++) hbuf[j] = make_float2((float)cr[j], (float)ci[j]);
+        for (int pos = 0; pos < M; pos++) {                               // the DIF output order
+            unsigned rv = 0;
+            for (int b = 0; b < logM; b++) if (pos & (1 << b)) rv |= 1u << (logM - 1 - b);
+            hbuf[(size_t)n + pos] = make_float2((float)fr[rv], (float)fi[rv]);
+        }
+        float2* dbuf = nullptr;
+        MIS_HIP(ctx, hipMalloc((void**)&dbuf, hbuf.size() * sizeof(float2)));
+        MIS_HIP(ctx, hipMemcpyAsync(dbuf, hbuf.data(), hbuf.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+        MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        it = w->chirp.emplace(n, dbuf).first;
+    }
+    d->chirp = it->second;
+    d->filt = it->second + n;
+    return MIS_OK;
+}
+
+static int launch_dft(mis_ctx* ctx, float2* data, const XgDft& d, int nseq, int per_batch, size_t batch_stride, int inverse)
+{
+    const size_t sh = (size_t)d.M * sizeof(float2);
+    if (sh > 64 * 1024)
+        MIS_HIP(ctx, hipFuncSetAttribute((const void*)xg_dft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL(xg_dft_rows, dim3((unsigned)nseq), dim3(d.M >= 2048 ? 512 : 256), sh, ctx->stream,
+                       data, d, per_batch, batch_stride, inverse);
+    return MIS_OK;
+}
 
 static int make_plan(mis_ctx* ctx, int w, int h, XcPlan* p)
 {
-    if (!is_pow2(w) || !is_pow2(h) || w < 16 || h < 16 || w > 8192 || h > 8192)
-        return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "tile size %d x %d: both sides must be powers of two in 16..8192", w, h);
-    p->w = w; p->h = h; p->logw = ilog2(w); p->logh = ilog2(h);
+    p->w = w; p->h = h;
+    p->general = !(is_pow2(w) && is_pow2(h) && w >= 16 && h >= 16 && w <= 8192 && h <= 8192);
+    if (p->general) {
+        const int lim_w = is_pow2(w) ? 16384 : 8192, lim_h = is_pow2(h) ? 16384 : 8192;
+        if (w < 1 || h < 1 || w > lim_w || h > lim_h)
+            return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "tile size %d x %d: sides up to 8192 (16384 for powers of two) are supported", w, h);
+        p->logw = p->logh = 0; p->RBw = p->CB = 1;
+        return MIS_OK;
+    }
+    p->logw = ilog2(w); p->logh = ilog2(h);
     p->RBw = w >= 2048 ? 1 : 2048 / w;          // rows per workgroup: 2048 complex values in LDS
     if (p->RBw > h) p->RBw = h;
     p->CB = h >= 4096 ? 1 : 4096 / h;           // columns per workgroup: 2 x 4096 complex values
@@ -472,6 +690,8 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
     {
         const size_t sh = (size_t)(152 + 2 * w + XC_GAUSS_K) * sizeof(float);
+        if (sh > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, surf, tmp);
     }
     hipLaunchKernelGGL(xc_colblur_argmax, dim3((w + 63) / 64, (h + XC_RB5 - 1) / XC_RB5, nt), dim3(256), 0, s,
@@ -481,7 +701,56 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
     return MIS_OK;
 }
 
-static size_t bytes_per_tile(const XcPlan& p) { return (size_t)p.w * p.h * (2 * sizeof(float2) + 3 * sizeof(float)); }
+// general-size variant of run_batch: stages 1-3 by row DFTs and transposes, stages 4-6 shared
+static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const mis_rect* d_r2,
+                             int tile0, int nt, mis_offset* d_out, float* dog_dbg, bool peak_stages)
+{
+    XcorrWs* ws = ctx->xc;
+    const int w = p.w, h = p.h;
+    const size_t N = (size_t)w * h;
+    XgDft dw, dh;
+    int rc = get_dft(ctx, w, &dw); if (rc) return rc;
+    rc = get_dft(ctx, h, &dh); if (rc) return rc;
+    float2* spec = (float2*)ws->buf;                                   // [nt][2][h][w]
+    float* surf = (float*)((char*)ws->buf + (size_t)nt * 2 * N * sizeof(float2));   // [nt][h][w]
+    float* tmp = surf + (size_t)nt * N;                                // [nt][h][w]
+    float2* specT = (float2*)(tmp + (size_t)nt * N);                   // [nt][2][w][h]
+    unsigned* minmax = (unsigned*)ws->meta;
+    unsigned long long* keys = (unsigned long long*)((char*)ws->meta + (((size_t)nt * 8 + 255) & ~(size_t)255));
+    hipStream_t s = ctx->stream;
+    const float scale = (float)(1.0 / sqrt((double)N));
+    hipLaunchKernelGGL(xc_init_meta, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax, keys);
+    XcImage im;
+    im.img[0] = ctx->img[0]; im.img[1] = ctx->img[1];
+    im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
+    hipLaunchKernelGGL(xg_load_tiles, dim3((w + 255) / 256, h, 2 * nt), dim3(256), 0, s, im, d_r1, d_r2, tile0, w, h, spec);
+    const dim3 tgrid((w + 31) / 32, (h + 31) / 32, 1), tgridT((h + 31) / 32, (w + 31) / 32, 1);
+    rc = launch_dft(ctx, spec, dw, 2 * nt * h, 2 * nt * h, 0, 0); if (rc) return rc;
+    hipLaunchKernelGGL(xg_transpose, dim3(tgrid.x, tgrid.y, 2 * nt), dim3(256), 0, s, spec, specT, h, w, N, N);
+    rc = launch_dft(ctx, specT, dh, 2 * nt * w, 2 * nt * w, 0, 0); if (rc) return rc;
+    hipLaunchKernelGGL(xg_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, specT, N, scale);
+    rc = launch_dft(ctx, specT, dh, nt * w, w, 2 * N, 1); if (rc) return rc;
+    hipLaunchKernelGGL(xg_transpose, dim3(tgridT.x, tgridT.y, nt), dim3(256), 0, s, specT, spec, w, h, 2 * N, 2 * N);
+    rc = launch_dft(ctx, spec, dw, nt * h, h, 2 * N, 1); if (rc) return rc;
+    hipLaunchKernelGGL(xg_abs_minmax, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, spec, N, scale, surf, minmax);
+    if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
+    {
+        const size_t sh = (size_t)(152 + 2 * w + XC_GAUSS_K) * sizeof(float);
+        if (sh > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, surf, tmp);
+    }
+    hipLaunchKernelGGL(xc_colblur_argmax, dim3((w + 63) / 64, (h + XC_RB5 - 1) / XC_RB5, nt), dim3(256), 0, s,
+                       w, h, ws->gauss, surf, tmp, dog_dbg, keys);
+    hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, surf, d_out + tile0);
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+static size_t bytes_per_tile(const XcPlan& p)
+{
+    return (size_t)p.w * p.h * ((p.general ? 4 : 2) * sizeof(float2) + 3 * sizeof(float));
+}
 
 static int xcorr_run(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, int n, int tile_w, int tile_h,
                      mis_offset* d_out, float* dog_dbg, bool peak_stages = true)
@@ -505,7 +774,8 @@ static int xcorr_run(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, i
     rc = mis_reserve(ctx, &ws->meta, &ws->meta_bytes, (size_t)nb * 16 + 512); if (rc) return rc;
     for (int t0 = 0; t0 < n; t0 += nb) {
         const int nt = (n - t0 < nb) ? n - t0 : nb;
-        rc = run_batch(ctx, p, d_r1, d_r2, t0, nt, d_out, dog_dbg, peak_stages);
+        rc = p.general ? run_batch_general(ctx, p, d_r1, d_r2, t0, nt, d_out, dog_dbg, peak_stages)
+                       : run_batch(ctx, p, d_r1, d_r2, t0, nt, d_out, dog_dbg, peak_stages);
         if (rc) return rc;
     }
     return MIS_OK;
@@ -563,7 +833,10 @@ __global__ __launch_bounds__(256) void xc_quantise_shift(int w, int h, const uns
     const float mn = __uint_as_float(minmax[0]), mx = __uint_as_float(minmax[1]);
     const double v = floor((((double)surf[(size_t)y * w + x] - (double)mn) / (double)(mx - mn)) * 255.0);
     const uint8_t b = (mx == mn || !(v >= 0)) ? 0 : (uint8_t)v;
-    const int xs = (x + w / 2) % w, ys = (y + h / 2) % h;
+    // swap of the two halves of length floor(n/2); an odd last row / column stays (image-cross-cor.cpp:52-80)
+    const int hw = w / 2, hh = h / 2;
+    const int xs = x < hw ? x + hw : (x < 2 * hw ? x - hw : x);
+    const int ys = y < hh ? y + hh : (y < 2 * hh ? y - hh : y);
     out[(size_t)ys * w + xs] = b;
 }
 
@@ -638,10 +911,34 @@ int mis_fft2d_forward(mis_ctx* ctx, const void* in, int dtype, int w, int h, int
     int rc = ensure_ws(ctx); if (rc) return rc;
     XcPlan p;
     rc = make_plan(ctx, w, h, &p); if (rc) return rc;
+    const size_t N = (size_t)w * h;
+    if (p.general) {
+        XgDft dw, dh;
+        rc = get_dft(ctx, w, &dw); if (rc) return rc;
+        rc = get_dft(ctx, h, &dh); if (rc) return rc;
+        XcorrWs* ws = ctx->xc;
+        rc = mis_reserve(ctx, &ws->buf, &ws->buf_bytes, N * (bpp + 2 * sizeof(float2))); if (rc) return rc;
+        hipStream_t s = ctx->stream;
+        float2* t1 = (float2*)ws->buf;
+        float2* t2 = t1 + N;
+        void* din = (void*)(t2 + N);
+        for (int b = 0; b < batch; b++) {
+            MIS_HIP(ctx, hipMemcpyAsync(din, (const char*)in + (size_t)b * N * bpp, N * bpp, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(xg_load_raster, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, din, dtype, N, t1);
+            rc = launch_dft(ctx, t1, dw, h, h, 0, 0); if (rc) return rc;
+            hipLaunchKernelGGL(xg_transpose, dim3((w + 31) / 32, (h + 31) / 32, 1), dim3(256), 0, s, t1, t2, h, w, N, N);
+            rc = launch_dft(ctx, t2, dh, w, w, 0, 0); if (rc) return rc;
+            hipLaunchKernelGGL(xg_transpose, dim3((h + 31) / 32, (w + 31) / 32, 1), dim3(256), 0, s, t2, t1, w, h, N, N);
+            hipLaunchKernelGGL(xg_divide, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, t1, N, sqrt((double)N));
+            MIS_HIP(ctx, hipGetLastError());
+            MIS_HIP(ctx, hipMemcpyAsync(out_complex + (size_t)b * N * 2, t1, N * sizeof(float2), hipMemcpyDeviceToHost, s));
+            MIS_HIP(ctx, hipStreamSynchronize(s));
+        }
+        return MIS_OK;
+    }
     const float2 *tww = nullptr, *twh = nullptr;
     rc = get_twiddle(ctx, w, &tww); if (rc) return rc;
     rc = get_twiddle(ctx, h, &twh); if (rc) return rc;
-    const size_t N = (size_t)w * h;
     int CB = 8192 / h; if (CB > 16) CB = 16; if (CB > w) CB = w; if (CB < 1) CB = 1;   // one array of <= 8192 values in LDS
     // rasters are processed in groups that fit a 2 GiB workspace
     const size_t per = N * (bpp + 2 * sizeof(float2));

@@ -25,7 +25,6 @@ struct Node {
 };
 
 int pow2_floor(int v) { int r = 0; while (v >>= 1) r++; return 1 << r; }
-bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
 
@@ -54,7 +53,6 @@ int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_s
         std::vector<mis_offset> off(level.size());
         for (auto& kv : by_size) {
             const int w = kv.first.first, h = kv.first.second;
-            if (!is_pow2(w) || !is_pow2(h)) return MIS_ERR_UNSUPPORTED;   // only possible at the first level
             std::vector<mis_rect> r1, r2;
             for (int i : kv.second) { r1.push_back(level[i].b1); r2.push_back(level[i].b2); }
             std::vector<mis_offset> o(r1.size());

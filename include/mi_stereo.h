@@ -97,7 +97,9 @@ int mis_ncc_dense_rows_device(mis_ctx* ctx, int window, int dmin, int dmax, int 
  * tile r1[i] of image 1 and r2[i] of image 2, zero-padded to tile_w x tile_h, are correlated
  * over all circular shifts; the |c| surface is min-max normalised, the 151-tap sigma-99
  * Gaussian is subtracted and the first maximum of the difference gives (dx,dy).
- * tile_w, tile_h: powers of two, 16..8192. */
+ * tile_w, tile_h: any size up to 8192 (powers of two up to 16384).  Powers of two in 16..8192
+ * run entirely in LDS-resident radix-2 transforms; other sizes (the reference's first level is
+ * the whole raster) go through chirp-z row transforms and are slower per pixel. */
 int mis_xcorr_tiles(mis_ctx* ctx, const mis_rect* r1, const mis_rect* r2, int n,
                     int tile_w, int tile_h, mis_offset* out);
 int mis_xcorr_tiles_device(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, int n,
@@ -109,13 +111,14 @@ int mis_xcorr_tile_surfaces(mis_ctx* ctx, mis_rect r1, mis_rect r2, int tile_w, 
 
 /* image-fft.cpp:45-105 (CalcFFT): forward 2-D DFT of `batch` real rasters of w x h pixels
  * (contiguous, row stride w), each value divided by sqrt(w*h); out: batch*w*h complex64
- * (interleaved re,im).  Host pointers.  w, h powers of two. */
+ * (interleaved re,im).  Host pointers.  w, h: as for mis_xcorr_tiles. */
 int mis_fft2d_forward(mis_ctx* ctx, const void* in, int dtype, int w, int h, int batch,
                       float* out_complex);
 
 /* image-cross-cor.cpp:104-186 (CalcFFT) for the bound pair: whole-image correlation surface
  * quantised floor(v*255) and fft-shifted (image-cross-cor.cpp:166-170).  out: w*h bytes, host.
- * Image size must be a power of two in both dimensions. */
+ * Image sides: as for mis_xcorr_tiles; odd sizes keep the reference's fft2shift behaviour (the
+ * last row / column is not moved, image-cross-cor.cpp:52-80). */
 int mis_xcorr_surface_u8(mis_ctx* ctx, uint8_t* out);
 
 /* ---- triangulation -------------------------------------------------------------------------
@@ -146,7 +149,7 @@ typedef struct {
  * depth-first: every recursion level is one batched mis_xcorr_tiles call per tile size.  Leaves
  * come back in the reference's depth-first visiting order.  *n_leaves is the total even when it
  * exceeds max_leaves; *n_tiles (nullable) counts findOffset evaluations.  The first level's tile
- * is the whole raster and must have power-of-two sides (MIS_ERR_UNSUPPORTED otherwise); "no
+ * is the whole raster (any size mis_xcorr_tiles takes); "no
  * overlap" (image3.cpp:710-712) returns MIS_ERR_STATE. */
 int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_size,
                       mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles);

@@ -69,3 +69,19 @@ def test_xyz_file_and_disparity_bands(ctx, tmp_path):
     cx, cy = last[0] + last[2] // 2, last[1] + last[3] // 2
     assert ras[1, cy, cx] == last[4] and ras[2, cy, cx] == last[5]
     assert ras[0, cy, cx] == np.float32(np.sqrt(np.float32(last[4] * last[4] + last[5] * last[5])))
+
+
+def test_frame_that_is_not_a_power_of_two(ctx):
+    """360 x 250 pair: the first level correlates the whole frames (any size), the levels below are
+    power-of-two tiles (image3.cpp:754-761)."""
+    big = synth.texture(250 + 40, 360 + 40, 91)
+    img2 = np.ascontiguousarray(big[20:270, 20:380])
+    img1 = np.ascontiguousarray(big[20 + 5:270 + 5, 20 - 9:380 - 9])     # content moved by (+9, -5)
+    ctx.upload_pair(img1, img2)
+    got, ntiles = ctx.disparity_map(min_size=16)
+    want, ncalls = oracle.disparity_map(img1, img2, min_size=16, precision=1)
+    assert ntiles == ncalls and len(got) == len(want) > 1
+    for g, w in zip(got, want):
+        assert g[:10] == w[:10]
+        assert abs(g[10] - w[10]) <= 1e-4 * max(abs(w[10]), 1e-3) + 1e-5
+    assert (got[0][4], got[0][5]) == (9, -5)

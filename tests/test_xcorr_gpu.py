@@ -118,3 +118,56 @@ def test_large_tile_2048(ctx):
     ctx.upload_pair(img1, img2)
     peak, ox, oy = ctx.find_offset((0, 0, 2048, 2048), (0, 0, 2048, 2048), 2048, 2048)
     assert (ox, oy) == (-100, 57) and peak == pytest.approx(1.0, abs=1e-5)
+
+
+@pytest.mark.parametrize("w,h,dx,dy", [
+    (100, 60, 7, -4),      # neither side a power of two
+    (96, 64, -11, 5),      # one side a power of two
+    (127, 33, 3, 2),       # odd sides: the last row / column is excluded from the peak search
+    (200, 200, -25, 31),
+    (8, 12, 1, -1),        # narrower than the blur radius: multiple reflections
+    (300, 1, 5, 0),        # one row: the blur kernel collapses in that dimension
+])
+def test_find_offset_general_sizes(ctx, w, h, dx, dy):
+    """Tile sides that are not powers of two (the first level of image3.cpp's recursion works on the
+    whole rasters): chirp-z row transforms against the oracle's mixed radix-2 / Bluestein FFT."""
+    img1, img2 = _pair(h, w, dx, dy, 300 + w)
+    ctx.upload_pair(img1, img2)
+    peak, ox, oy = ctx.find_offset((0, 0, w, h), (0, 0, w, h), w, h)
+    ref = oracle.find_offset(img1, img2, (0, 0, w, h), (0, 0, w, h), w, h, precision=1, want_surface=True, want_dog=True)
+    assert (ox, oy) == (ref["dx"], ref["dy"])
+    if min(w, h) >= 60:
+        assert (ox, oy) == (dx, dy)
+    assert abs(peak - ref["peak"]) <= 1e-4 * max(abs(ref["peak"]), 1e-3) + 1e-5
+    surf, dog = ctx.tile_surfaces((0, 0, w, h), (0, 0, w, h), w, h)
+    assert np.abs(surf - ref["surface"]).max() <= 3e-5
+    assert np.abs(dog - ref["dog"]).max() <= 1e-4
+
+
+def test_general_size_large_frame(ctx):
+    """A 3000 x 2000 frame as one tile (transform lengths 8192 and 4096 internally)."""
+    w, h = 3000, 2000
+    img1, img2 = _pair(h, w, -140, 77, 12)
+    ctx.upload_pair(img1, img2)
+    peak, ox, oy = ctx.find_offset((0, 0, w, h), (0, 0, w, h), w, h)
+    assert (ox, oy) == (-140, 77) and peak == pytest.approx(1.0, abs=1e-4)
+
+
+def test_fft2d_forward_general_sizes(ctx):
+    rng = np.random.default_rng(12)
+    for shape in ((60, 100), (33, 127), (64, 96), (1, 50)):
+        img = rng.integers(0, 65536, shape).astype(np.uint16)
+        got = ctx.fft2d_forward(img)
+        want = np.fft.fft2(img.astype(np.float64)) / np.sqrt(shape[0] * shape[1])
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 2e-5, shape
+
+
+def test_xcorr_surface_u8_odd_size(ctx):
+    """Odd sizes: fft2shift swaps halves of floor(n/2) and leaves the last row / column in place
+    (image-cross-cor.cpp:52-80)."""
+    img1, img2 = _pair(75, 101, 8, -6, 19)
+    ctx.upload_pair(img1, img2)
+    got = ctx.xcorr_surface_u8().astype(np.int32)
+    want = oracle.xcorr_surface_u8(img1, img2, precision=1).astype(np.int32)
+    d = np.abs(got - want)
+    assert d.max() <= 1 and (d > 0).mean() <= 0.02
