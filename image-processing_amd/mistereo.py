@@ -52,7 +52,7 @@ EXPORTS = [
     "mis_xcorr_tiles", "mis_xcorr_tiles_device", "mis_xcorr_tile_surfaces",
     "mis_fft2d_forward", "mis_xcorr_surface_u8",
     "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
-    "mis_disparity_map", "mis_write_xyz", "mis_rasterize_leaves",
+    "mis_disparity_map", "mis_write_xyz", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
     "mis_profile_enable", "mis_profile_read", "mis_version",
 ]
 
@@ -144,6 +144,29 @@ def write_xyz(path, xyz, bands=None, append=False):
                            1 if append else 0)
     if rc != 0:
         raise MisError(rc, "mis_write_xyz failed for %s" % path)
+
+
+def write_tiff_f32(path, planes):
+    """Band-interleaved Float32 TIFF as the reference creates through GDAL (image3.cpp:872-893).
+    planes: [bands, H, W] (or [H, W])."""
+    lib = load_library()
+    planes = np.ascontiguousarray(planes, np.float32)
+    if planes.ndim == 2:
+        planes = planes[None]
+    b, h, w = planes.shape
+    rc = lib.mis_write_tiff_f32(os.fsencode(path), _np_ptr(planes), w, h, b)
+    if rc != 0:
+        raise MisError(rc, "mis_write_tiff_f32 failed for %s" % path)
+
+
+def load_camera_yaml(path):
+    """Camera of image3.cpp:1014-1030: the A, R, T matrices of an OpenCV FileStorage YAML file."""
+    lib = load_library()
+    cam = Camera()
+    rc = lib.mis_load_camera_yaml(os.fsencode(path), C.byref(cam))
+    if rc != 0:
+        raise MisError(rc, "mis_load_camera_yaml failed for %s" % path)
+    return cam
 
 
 def rasterize_leaves(records, width, height, fill=0.0):

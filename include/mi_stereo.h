@@ -163,6 +163,18 @@ int mis_write_xyz(const char* path, const float* xyz, int n, const float* bands,
  * width*height floats (INTERLEAVE=BAND). */
 int mis_rasterize_leaves(const mis_leaf* leaves, int n, int width, int height, float* out);
 
+/* The TIFF image3.cpp creates through GDAL (CreateOutputDataset, image3.cpp:872-893: GTiff,
+ * Float32, INTERLEAVE=BAND, no georeferencing): `bands` planes of width*height floats, one strip
+ * per band, PlanarConfiguration=2, SampleFormat=IEEE float; BigTIFF when the pixels exceed 4 GiB.
+ * Pixels no leaf covered are whatever the caller put in `planes` (GDAL leaves them 0). */
+int mis_write_tiff_f32(const char* path, const float* planes, int width, int height, int bands);
+
+/* Camera file of image3.cpp:1014-1030: OpenCV FileStorage YAML "<image>.yaml" with the
+ * !!opencv-matrix nodes A (3x3), R (3x3) and T (3x1), any element type, converted to float as
+ * Mat::assignTo(CV_32F) does.  MIS_ERR_STATE: file cannot be opened; MIS_ERR_ARG: a node is
+ * missing or has the wrong size. */
+int mis_load_camera_yaml(const char* path, mis_camera* cam);
+
 /* ---- device timing (no counterpart in the reference, which has no timing code) ----------------
  * While enabled, every dense-NCC call records HIP events on the context's stream around its
  * table-building kernels, its main correlation (argmax) kernel and its refinement kernel.

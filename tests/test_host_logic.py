@@ -133,3 +133,87 @@ def test_bench_gather_pipeline_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+OPENCV_YAML = """%YAML:1.0
+A: !!opencv-matrix
+   rows: 3
+   cols: 3
+   dt: d
+   data: [ 1.0000000000000000e+04, 0., 4.0965000000000000e+03, 0.,
+       1.0000250000000000e+04, 3.1205000000000000e+03, 0., 0., 1. ]
+R: !!opencv-matrix
+   rows: 3
+   cols: 3
+   dt: f
+   data: [ 9.99847710e-01, -1.74524058e-02, 0., 1.74524058e-02,
+       9.99847710e-01, 0., 0., 0., 1. ]
+T: !!opencv-matrix
+   rows: 3
+   cols: 1
+   dt: d
+   data: [ -9.0012345678901234e+02, .5, -3000. ]
+"""
+
+
+def test_camera_yaml_reader(tmp_path):
+    """OpenCV FileStorage YAML as image3.cpp:1014-1030 reads it (A, R, T; doubles narrowed to float)."""
+    import mistereo
+    path = os.path.join(tmp_path, "left.tif.yaml")
+    with open(path, "w") as f:
+        f.write(OPENCV_YAML)
+    cam = mistereo.load_camera_yaml(path)
+    A = np.array(cam.A[:], np.float32).reshape(3, 3)
+    assert np.array_equal(A, np.array([[1e4, 0, 4096.5], [0, 10000.25, 3120.5], [0, 0, 1]], np.float32))
+    R = np.array(cam.R[:], np.float32).reshape(3, 3)
+    assert R[0, 0] == np.float32(9.99847710e-01) and R[0, 1] == np.float32(-1.74524058e-02) and R[2, 2] == 1
+    assert np.array_equal(np.array(cam.T[:], np.float32),
+                          np.array([-9.0012345678901234e+02, 0.5, -3000.0]).astype(np.float32))
+    with pytest.raises(mistereo.MisError):
+        mistereo.load_camera_yaml(os.path.join(tmp_path, "missing.yaml"))
+    bad = os.path.join(tmp_path, "bad.yaml")
+    with open(bad, "w") as f:
+        f.write(OPENCV_YAML.replace("T: !!opencv-matrix", "Q: !!opencv-matrix"))
+    with pytest.raises(mistereo.MisError):
+        mistereo.load_camera_yaml(bad)
+
+
+def _read_tiff(path):
+    """Minimal classic-TIFF reader for the tags the writer emits."""
+    import struct
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"II*\x00"
+    (ifd,) = struct.unpack_from("<I", raw, 4)
+    (n,) = struct.unpack_from("<H", raw, ifd)
+    size = {3: 2, 4: 4}
+    tags = {}
+    for i in range(n):
+        tid, typ, cnt, val = struct.unpack_from("<HHII", raw, ifd + 2 + 12 * i)
+        if size[typ] * cnt <= 4:
+            vals = list(struct.unpack_from("<%d%s" % (cnt, "H" if typ == 3 else "I"), raw, ifd + 2 + 12 * i + 8))
+        else:
+            vals = list(struct.unpack_from("<%d%s" % (cnt, "H" if typ == 3 else "I"), raw, val))
+        tags[tid] = vals
+    return raw, tags
+
+
+def test_tiff_writer_band_interleaved_float32(tmp_path):
+    """3-band Float32 TIFF with INTERLEAVE=BAND (image3.cpp:872-893)."""
+    import mistereo
+    rng = np.random.default_rng(4)
+    planes = rng.normal(size=(3, 37, 53)).astype(np.float32)
+    path = os.path.join(tmp_path, "disp.tif")
+    mistereo.write_tiff_f32(path, planes)
+    raw, tags = _read_tiff(path)
+    assert tags[256] == [53] and tags[257] == [37]
+    assert tags[258] == [32, 32, 32] and tags[339] == [3, 3, 3]       # Float32 samples
+    assert tags[277] == [3] and tags[284] == [2] and tags[259] == [1]  # 3 samples, planar, uncompressed
+    assert tags[279] == [37 * 53 * 4] * 3
+    for b in range(3):
+        got = np.frombuffer(raw, np.float32, 37 * 53, tags[273][b]).reshape(37, 53)
+        assert np.array_equal(got, planes[b])
+    # a single band is readable by an independent TIFF reader
+    from PIL import Image
+    one = os.path.join(tmp_path, "one.tif")
+    mistereo.write_tiff_f32(one, planes[0])
+    assert np.array_equal(np.asarray(Image.open(one)), planes[0])
