@@ -22,6 +22,10 @@ struct mis_ctx {
     int dtype = -1, width = 0, height = 0;
     size_t stride = 0;                            // bytes
     uint64_t pair_serial = 0;                     // bumped on every bind/upload
+    // further bands of the same two rasters (tile correlation only): device pointers, same
+    // type / size / stride as img[]; dropped whenever a new pair is bound
+    std::vector<const void*> band_img[2];
+    std::vector<void*> owned_bands;               // set when mis_upload_extra_bands allocated them
 
     // dense-NCC workspace (see ncc_kernels.hip)
     struct NccWs* ncc = nullptr;

@@ -121,6 +121,7 @@ int mis_destroy(mis_ctx* ctx)
     if (ctx->tri_buf) (void)hipFree(ctx->tri_buf);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) if (ctx->owned_img[i]) (void)hipFree(ctx->owned_img[i]);
+    for (void* p : ctx->owned_bands) (void)hipFree(p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MIS_OK;
@@ -148,6 +149,13 @@ int mis_synchronize(mis_ctx* ctx)
     return MIS_OK;
 }
 
+static void drop_extra_bands(mis_ctx* ctx)
+{
+    ctx->band_img[0].clear(); ctx->band_img[1].clear();
+    for (void* p : ctx->owned_bands) (void)hipFree(p);
+    ctx->owned_bands.clear();
+}
+
 static int check_pair_args(mis_ctx* ctx, const void* a, const void* b, int dtype, int w, int h, size_t stride)
 {
     if (!ctx) return MIS_ERR_ARG;
@@ -165,6 +173,7 @@ int mis_bind_pair_device(mis_ctx* ctx, const void* d_img1, const void* d_img2, i
 {
     int rc = check_pair_args(ctx, d_img1, d_img2, dtype, width, height, row_stride_bytes);
     if (rc) return rc;
+    drop_extra_bands(ctx);
     ctx->img[0] = d_img1; ctx->img[1] = d_img2;
     ctx->dtype = dtype; ctx->width = width; ctx->height = height; ctx->stride = row_stride_bytes;
     ctx->pair_serial++;
@@ -193,6 +202,43 @@ int mis_upload_pair(mis_ctx* ctx, const void* img1, const void* img2, int dtype,
                                       hipMemcpyHostToDevice, ctx->stream));
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return mis_bind_pair_device(ctx, ctx->owned_img[0], ctx->owned_img[1], dtype, width, height, rowb);
+}
+
+int mis_set_extra_bands_device(mis_ctx* ctx, int n_extra, const void* const* d_img1, const void* const* d_img2)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "extra bands: bind the first band with mis_upload_pair / mis_bind_pair_device first");
+    if (n_extra < 0 || n_extra > 15 || (n_extra > 0 && (!d_img1 || !d_img2))) return mis_fail(ctx, MIS_ERR_ARG, "extra bands: bad arguments");
+    for (int i = 0; i < n_extra; i++)
+        if (!d_img1[i] || !d_img2[i]) return mis_fail(ctx, MIS_ERR_ARG, "extra bands: band %d is NULL", i + 2);
+    drop_extra_bands(ctx);
+    for (int i = 0; i < n_extra; i++) { ctx->band_img[0].push_back(d_img1[i]); ctx->band_img[1].push_back(d_img2[i]); }
+    return MIS_OK;
+}
+
+int mis_upload_extra_bands(mis_ctx* ctx, int n_extra, const void* const* img1, const void* const* img2, size_t row_stride_bytes)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "extra bands: bind the first band with mis_upload_pair / mis_bind_pair_device first");
+    if (n_extra < 0 || n_extra > 15 || (n_extra > 0 && (!img1 || !img2))) return mis_fail(ctx, MIS_ERR_ARG, "extra bands: bad arguments");
+    const size_t rowb = (size_t)ctx->width * mis_pixel_bytes(ctx->dtype);
+    if (row_stride_bytes < rowb) return mis_fail(ctx, MIS_ERR_ARG, "extra bands: row stride smaller than a row");
+    if (ctx->stride != rowb) return mis_fail(ctx, MIS_ERR_STATE, "extra bands: the bound pair must be tightly packed (upload it with mis_upload_pair)");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    drop_extra_bands(ctx);
+    for (int i = 0; i < n_extra; i++) {
+        const void* src[2] = { img1[i], img2[i] };
+        for (int s = 0; s < 2; s++) {
+            if (!src[s]) return mis_fail(ctx, MIS_ERR_ARG, "extra bands: band %d is NULL", i + 2);
+            void* d = nullptr;
+            MIS_HIP(ctx, hipMalloc(&d, rowb * ctx->height));
+            ctx->owned_bands.push_back(d);
+            MIS_HIP(ctx, hipMemcpy2DAsync(d, rowb, src[s], row_stride_bytes, rowb, ctx->height, hipMemcpyHostToDevice, ctx->stream));
+            ctx->band_img[s].push_back(d);
+        }
+    }
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MIS_OK;
 }
 
 }  // extern "C"

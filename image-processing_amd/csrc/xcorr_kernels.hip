@@ -30,6 +30,7 @@ struct XcorrWs {
     float* gauss = nullptr;             // 151 taps
     void* buf = nullptr; size_t buf_bytes = 0;      // spectra / surfaces of one batch of tiles
     void* meta = nullptr; size_t meta_bytes = 0;    // per-tile min/max, argmax keys, rects
+    const float* last_surface = nullptr;            // normalised surfaces of the last batch (inspection)
 };
 
 void mis_xcorr_release(mis_ctx* ctx)
@@ -277,7 +278,7 @@ __device__ __forceinline__ int reflect101(int p, int len)
 // to right with separate multiply and add.
 __global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsigned* __restrict__ minmax,
                                                        const float* __restrict__ gauss,
-                                                       float* __restrict__ surf, float* __restrict__ tmp)
+                                                       float* __restrict__ surf, float* __restrict__ tmp, int pre)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* g = (float*)smem_raw;                    // 151 taps (152 slots)
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsig
     for (int i = threadIdx.x; i < XC_GAUSS_K; i += blockDim.x) g[i] = gauss[i];
     for (int x = threadIdx.x; x < w; x += blockDim.x) {
         const float m = srow[x];
-        const float o = (float)(((double)m - (double)mn) / (double)range);
+        // pre: the surface already holds the product of the normalised band surfaces
+        const float o = pre ? m : (float)(((double)m - (double)mn) / (double)range);
         srow[x] = o;                                 // the normalised surface, kept for stage 5
         nrow[x] = o;
     }
@@ -546,6 +548,49 @@ __global__ __launch_bounds__(256) void xg_divide(float2* __restrict__ x, size_t 
     x[i] = make_float2((float)((double)v.x / norm), (float)((double)v.y / norm));
 }
 
+// Band loop of image3.cpp:382-418 with n_bands not forced to 1: prod = prod * norm(band), the
+// product evaluated in double and narrowed (image3.cpp:414-416); first != 0 starts from 1.0.
+__global__ __launch_bounds__(256) void xc_band_product(size_t N, const unsigned* __restrict__ minmax,
+                                                       const float* __restrict__ surf, float* __restrict__ prod, int first)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (i >= N) return;
+    const float mn = __uint_as_float(minmax[2 * t]), mx = __uint_as_float(minmax[2 * t + 1]);
+    const double v = ((double)surf[(size_t)t * N + i] - (double)mn) / (double)(mx - mn);   // 0/0 -> NaN
+    const float prev = first ? 1.0f : prod[(size_t)t * N + i];
+    prod[(size_t)t * N + i] = (float)((double)prev * v);
+}
+
+__global__ void xc_reset_minmax(int n, unsigned* minmax)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    minmax[2 * t] = 0x7F800000u;
+    minmax[2 * t + 1] = 0u;
+}
+
+// findCPPMax (image2.cpp:216-308, image-find-cpp.cpp:68-158): band product (left to right, float),
+// first strict maximum above -1 in row-major order outside the central mask rectangle.
+__global__ __launch_bounds__(256) void xc_masked_peak(const float* __restrict__ bands, int cols, int rows, int nb,
+                                                      int rows2, int cols2, int r0, int r1, int c0, int c1,
+                                                      unsigned long long* __restrict__ key)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    unsigned long long best = 0;
+    if (col < cols2 && row < rows2 && !(row >= r0 && row < r1 && col >= c0 && col < c1)) {
+        const size_t px = (size_t)rows * cols, o = (size_t)row * cols + col;
+        float v = bands[o];
+        for (int b = 1; b < nb; b++) v = __fmul_rn(v, bands[(size_t)b * px + o]);
+        if (v > -1.0f) best = argmax_key(v, (unsigned)o);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long other = __shfl_xor(best, o);
+        best = other > best ? other : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(key, best);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
@@ -658,45 +703,55 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
     float2* spec = (float2*)ws->buf;                                   // [nt][2][h][w]
     float* surf = (float*)((char*)ws->buf + (size_t)nt * 2 * N * sizeof(float2));   // [nt][h][w]
     float* tmp = surf + (size_t)nt * N;                                // [nt][h][w]
+    const int nbands = 1 + (int)ctx->band_img[0].size();
+    float* prod = tmp + (size_t)nt * N;                                // [nt][h][w], only with several bands
+    float* fsurf = nbands > 1 ? prod : surf;                           // what stages 4-6 work on
     unsigned* minmax = (unsigned*)ws->meta;
     unsigned long long* keys = (unsigned long long*)((char*)ws->meta + (((size_t)nt * 8 + 255) & ~(size_t)255));
     hipStream_t s = ctx->stream;
     const float scale = (float)(1.0 / sqrt((double)N));
+    ws->last_surface = fsurf;
 
     hipLaunchKernelGGL(xc_init_meta, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax, keys);
-    XcImage im;
-    im.img[0] = ctx->img[0]; im.img[1] = ctx->img[1];
-    im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
-    {
-        const size_t sh = (size_t)p.RBw * w * sizeof(float2);
-        if (sh > 64 * 1024) {
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_rows_inv_abs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    for (int band = 0; band < nbands; band++) {
+        XcImage im;
+        im.img[0] = band ? ctx->band_img[0][band - 1] : ctx->img[0];
+        im.img[1] = band ? ctx->band_img[1][band - 1] : ctx->img[1];
+        im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
+        if (band) hipLaunchKernelGGL(xc_reset_minmax, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax);
+        {
+            const size_t sh = (size_t)p.RBw * w * sizeof(float2);
+            if (sh > 64 * 1024) {
+                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_rows_inv_abs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            }
+            hipLaunchKernelGGL(xc_rows_fwd, dim3(h / p.RBw, 2, nt), dim3(256), sh, s, im, d_r1, d_r2, tile0,
+                               w, h, p.logw, p.RBw, tww, spec);
         }
-        hipLaunchKernelGGL(xc_rows_fwd, dim3(h / p.RBw, 2, nt), dim3(256), sh, s, im, d_r1, d_r2, tile0,
-                           w, h, p.logw, p.RBw, tww, spec);
-    }
-    {
-        const size_t sh = (size_t)2 * p.CB * h * sizeof(float2);
-        if (sh > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(xc_cols, dim3(w / p.CB, nt), dim3(512), sh, s, w, h, p.logh, p.CB, scale, twh, spec);
-    }
-    {
-        const size_t sh = (size_t)p.RBw * w * sizeof(float2);
-        hipLaunchKernelGGL(xc_rows_inv_abs, dim3(h / p.RBw, nt), dim3(256), sh, s, w, h, p.logw, p.RBw, scale,
-                           tww, spec, surf, minmax);
+        {
+            const size_t sh = (size_t)2 * p.CB * h * sizeof(float2);
+            if (sh > 64 * 1024)
+                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            hipLaunchKernelGGL(xc_cols, dim3(w / p.CB, nt), dim3(512), sh, s, w, h, p.logh, p.CB, scale, twh, spec);
+        }
+        {
+            const size_t sh = (size_t)p.RBw * w * sizeof(float2);
+            hipLaunchKernelGGL(xc_rows_inv_abs, dim3(h / p.RBw, nt), dim3(256), sh, s, w, h, p.logw, p.RBw, scale,
+                               tww, spec, surf, minmax);
+        }
+        if (nbands > 1)
+            hipLaunchKernelGGL(xc_band_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, N, minmax, surf, prod, band == 0);
     }
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
     {
         const size_t sh = (size_t)(152 + 2 * w + XC_GAUSS_K) * sizeof(float);
         if (sh > 64 * 1024)
             MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, surf, tmp);
+        hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
     }
     hipLaunchKernelGGL(xc_colblur_argmax, dim3((w + 63) / 64, (h + XC_RB5 - 1) / XC_RB5, nt), dim3(256), 0, s,
-                       w, h, ws->gauss, surf, tmp, dog_dbg, keys);
-    hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, surf, d_out + tile0);
+                       w, h, ws->gauss, fsurf, tmp, dog_dbg, keys);
+    hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, fsurf, d_out + tile0);
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
@@ -715,41 +770,51 @@ static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1
     float* surf = (float*)((char*)ws->buf + (size_t)nt * 2 * N * sizeof(float2));   // [nt][h][w]
     float* tmp = surf + (size_t)nt * N;                                // [nt][h][w]
     float2* specT = (float2*)(tmp + (size_t)nt * N);                   // [nt][2][w][h]
+    const int nbands = 1 + (int)ctx->band_img[0].size();
+    float* prod = (float*)(specT + (size_t)nt * 2 * N);                // [nt][h][w], only with several bands
+    float* fsurf = nbands > 1 ? prod : surf;
     unsigned* minmax = (unsigned*)ws->meta;
     unsigned long long* keys = (unsigned long long*)((char*)ws->meta + (((size_t)nt * 8 + 255) & ~(size_t)255));
     hipStream_t s = ctx->stream;
     const float scale = (float)(1.0 / sqrt((double)N));
+    ws->last_surface = fsurf;
     hipLaunchKernelGGL(xc_init_meta, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax, keys);
-    XcImage im;
-    im.img[0] = ctx->img[0]; im.img[1] = ctx->img[1];
-    im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
-    hipLaunchKernelGGL(xg_load_tiles, dim3((w + 255) / 256, h, 2 * nt), dim3(256), 0, s, im, d_r1, d_r2, tile0, w, h, spec);
     const dim3 tgrid((w + 31) / 32, (h + 31) / 32, 1), tgridT((h + 31) / 32, (w + 31) / 32, 1);
-    rc = launch_dft(ctx, spec, dw, 2 * nt * h, 2 * nt * h, 0, 0); if (rc) return rc;
-    hipLaunchKernelGGL(xg_transpose, dim3(tgrid.x, tgrid.y, 2 * nt), dim3(256), 0, s, spec, specT, h, w, N, N);
-    rc = launch_dft(ctx, specT, dh, 2 * nt * w, 2 * nt * w, 0, 0); if (rc) return rc;
-    hipLaunchKernelGGL(xg_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, specT, N, scale);
-    rc = launch_dft(ctx, specT, dh, nt * w, w, 2 * N, 1); if (rc) return rc;
-    hipLaunchKernelGGL(xg_transpose, dim3(tgridT.x, tgridT.y, nt), dim3(256), 0, s, specT, spec, w, h, 2 * N, 2 * N);
-    rc = launch_dft(ctx, spec, dw, nt * h, h, 2 * N, 1); if (rc) return rc;
-    hipLaunchKernelGGL(xg_abs_minmax, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, spec, N, scale, surf, minmax);
+    for (int band = 0; band < nbands; band++) {
+        XcImage im;
+        im.img[0] = band ? ctx->band_img[0][band - 1] : ctx->img[0];
+        im.img[1] = band ? ctx->band_img[1][band - 1] : ctx->img[1];
+        im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
+        if (band) hipLaunchKernelGGL(xc_reset_minmax, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax);
+        hipLaunchKernelGGL(xg_load_tiles, dim3((w + 255) / 256, h, 2 * nt), dim3(256), 0, s, im, d_r1, d_r2, tile0, w, h, spec);
+        rc = launch_dft(ctx, spec, dw, 2 * nt * h, 2 * nt * h, 0, 0); if (rc) return rc;
+        hipLaunchKernelGGL(xg_transpose, dim3(tgrid.x, tgrid.y, 2 * nt), dim3(256), 0, s, spec, specT, h, w, N, N);
+        rc = launch_dft(ctx, specT, dh, 2 * nt * w, 2 * nt * w, 0, 0); if (rc) return rc;
+        hipLaunchKernelGGL(xg_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, specT, N, scale);
+        rc = launch_dft(ctx, specT, dh, nt * w, w, 2 * N, 1); if (rc) return rc;
+        hipLaunchKernelGGL(xg_transpose, dim3(tgridT.x, tgridT.y, nt), dim3(256), 0, s, specT, spec, w, h, 2 * N, 2 * N);
+        rc = launch_dft(ctx, spec, dw, nt * h, h, 2 * N, 1); if (rc) return rc;
+        hipLaunchKernelGGL(xg_abs_minmax, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, spec, N, scale, surf, minmax);
+        if (nbands > 1)
+            hipLaunchKernelGGL(xc_band_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, N, minmax, surf, prod, band == 0);
+    }
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
     {
         const size_t sh = (size_t)(152 + 2 * w + XC_GAUSS_K) * sizeof(float);
         if (sh > 64 * 1024)
             MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, surf, tmp);
+        hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
     }
     hipLaunchKernelGGL(xc_colblur_argmax, dim3((w + 63) / 64, (h + XC_RB5 - 1) / XC_RB5, nt), dim3(256), 0, s,
-                       w, h, ws->gauss, surf, tmp, dog_dbg, keys);
-    hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, surf, d_out + tile0);
+                       w, h, ws->gauss, fsurf, tmp, dog_dbg, keys);
+    hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, fsurf, d_out + tile0);
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
 
 static size_t bytes_per_tile(const XcPlan& p)
 {
-    return (size_t)p.w * p.h * ((p.general ? 4 : 2) * sizeof(float2) + 3 * sizeof(float));
+    return (size_t)p.w * p.h * ((p.general ? 4 : 2) * sizeof(float2) + 4 * sizeof(float));
 }
 
 static int xcorr_run(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, int n, int tile_w, int tile_h,
@@ -891,7 +956,7 @@ int mis_xcorr_tile_surfaces(mis_ctx* ctx, mis_rect r1, mis_rect r2, int tile_w, 
     if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e));
     if (!rc) rc = xcorr_run(ctx, d1, d2, 1, tile_w, tile_h, dout, ddog);
     if (!rc) {
-        const float* surf = (const float*)((char*)ctx->xc->buf + 2 * N * sizeof(float2));
+        const float* surf = ctx->xc->last_surface;
         if (surface) e = hipMemcpyAsync(surface, surf, N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && dog) e = hipMemcpyAsync(dog, ddog, N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -965,6 +1030,51 @@ int mis_fft2d_forward(mis_ctx* ctx, const void* in, int dtype, int w, int h, int
         MIS_HIP(ctx, hipMemcpyAsync(out_complex + (size_t)b0 * N * 2, t2, (size_t)nt * N * sizeof(float2), hipMemcpyDeviceToHost, s));
         MIS_HIP(ctx, hipStreamSynchronize(s));
     }
+    return MIS_OK;
+}
+
+int mis_masked_peak(mis_ctx* ctx, const float* bands, int width, int height, int n_bands, float mask_pct,
+                    int* offset_x, int* offset_y, float* peak)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!bands || width < 1 || height < 1 || n_bands < 1 || !offset_x || !offset_y || !peak)
+        return mis_fail(ctx, MIS_ERR_ARG, "masked peak: bad arguments");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_ws(ctx); if (rc) return rc;
+    XcorrWs* ws = ctx->xc;
+    const size_t N = (size_t)width * height;
+    rc = mis_reserve(ctx, &ws->buf, &ws->buf_bytes, N * n_bands * sizeof(float)); if (rc) return rc;
+    rc = mis_reserve(ctx, &ws->meta, &ws->meta_bytes, 512); if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    // image2.cpp:248-263; the mask bounds are float expressions truncated on assignment
+    const int pp_row = height / 2, pp_col = width / 2;
+    if (mask_pct > 99) mask_pct = 99;
+    if (mask_pct <= 1) mask_pct = 0;
+    const int r0 = (int)((float)pp_row - ((float)pp_row * mask_pct / 100.0f));
+    const int r1 = (int)((float)pp_row + ((float)pp_row * mask_pct / 100.0f));
+    const int c0 = (int)((float)pp_col - ((float)pp_col * mask_pct / 100.0f));
+    const int c1 = (int)((float)pp_col + ((float)pp_col * mask_pct / 100.0f));
+    unsigned long long* key = (unsigned long long*)ws->meta;
+    MIS_HIP(ctx, hipMemcpyAsync(ws->buf, bands, N * n_bands * sizeof(float), hipMemcpyHostToDevice, s));
+    MIS_HIP(ctx, hipMemsetAsync(key, 0, sizeof *key, s));
+    hipLaunchKernelGGL(xc_masked_peak, dim3((width + 255) / 256, height), dim3(256), 0, s, (const float*)ws->buf,
+                       width, height, n_bands, pp_row * 2, pp_col * 2, r0, r1, c0, c1, key);
+    MIS_HIP(ctx, hipGetLastError());
+    unsigned long long k = 0;
+    MIS_HIP(ctx, hipMemcpyAsync(&k, key, sizeof k, hipMemcpyDeviceToHost, s));
+    MIS_HIP(ctx, hipStreamSynchronize(s));
+    int max_col = 0, max_row = 0;
+    float mx = -1.0f;                              // nothing above the initial -1 (image2.cpp:266-267)
+    if (k) {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFu);
+        unsigned b = (unsigned)(k >> 32);
+        b = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b;
+        memcpy(&mx, &b, 4);
+        max_col = (int)(idx % (unsigned)width); max_row = (int)(idx / (unsigned)width);
+    }
+    *offset_x = max_col - pp_col;                  // image2.cpp:301-302
+    *offset_y = max_row - pp_row;
+    *peak = mx;
     return MIS_OK;
 }
 

@@ -53,6 +53,7 @@ EXPORTS = [
     "mis_fft2d_forward", "mis_xcorr_surface_u8",
     "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
     "mis_disparity_map", "mis_write_xyz", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
+    "mis_set_extra_bands_device", "mis_upload_extra_bands", "mis_masked_peak",
     "mis_profile_enable", "mis_profile_read", "mis_version",
 ]
 
@@ -325,6 +326,33 @@ class Context:
         out = np.empty((b, h, w), np.complex64)
         self._check(self._lib.mis_fft2d_forward(self._h, _np_ptr(a), _dtype_code(a.dtype), w, h, b, _np_ptr(out)))
         return out[0] if single else out
+
+    def upload_extra_bands(self, bands1, bands2):
+        """Bands 2.. of the two rasters (lists of numpy rasters shaped like the uploaded pair): the
+        tile correlation multiplies the normalised surfaces of all bands (image3.cpp:382-418)."""
+        bands1 = [np.ascontiguousarray(b) for b in bands1]
+        bands2 = [np.ascontiguousarray(b) for b in bands2]
+        n = len(bands1)
+        if n != len(bands2):
+            raise ValueError("both rasters need the same number of bands")
+        for b in bands1 + bands2:
+            if b.shape != self.shape:
+                raise ValueError("extra bands must have the shape of the uploaded pair")
+        p1 = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bands1])
+        p2 = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bands2])
+        stride = bands1[0].strides[0] if n else 0
+        self._check(self._lib.mis_upload_extra_bands(self._h, n, p1, p2, C.c_size_t(stride)))
+
+    def masked_peak(self, bands, mask_pct):
+        """findCPPMax (image2.cpp:216-308): bands [n, rows, cols] float32 -> (peak, offset_x, offset_y)."""
+        bands = np.ascontiguousarray(bands, np.float32)
+        if bands.ndim == 2:
+            bands = bands[None]
+        nb, rows, cols = bands.shape
+        ox, oy, pk = C.c_int(0), C.c_int(0), C.c_float(0)
+        self._check(self._lib.mis_masked_peak(self._h, _np_ptr(bands), cols, rows, nb, C.c_float(mask_pct),
+                                              C.byref(ox), C.byref(oy), C.byref(pk)))
+        return float(pk.value), ox.value, oy.value
 
     def xcorr_surface_u8(self):
         h, w = self.shape

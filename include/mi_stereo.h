@@ -109,6 +109,23 @@ int mis_xcorr_tiles_device(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d
 int mis_xcorr_tile_surfaces(mis_ctx* ctx, mis_rect r1, mis_rect r2, int tile_w, int tile_h,
                             float* surface, float* dog);
 
+/* Further bands of the two rasters for mis_xcorr_tiles: the band loop of findOffset
+ * (image3.cpp:382-418) multiplies the normalised correlation surfaces of all bands, but the
+ * reference forces n_bands to 1 (image3.cpp:352-353), which is what a context without extra bands
+ * does.  n_extra (0..15) bands 2.. of image 1 and image 2, same pixel type and size as the bound
+ * pair; dropped when a new pair is bound.  The _device form keeps the caller's device pointers
+ * (same row stride as the bound pair), the other copies host rasters. */
+int mis_set_extra_bands_device(mis_ctx* ctx, int n_extra, const void* const* d_img1, const void* const* d_img2);
+int mis_upload_extra_bands(mis_ctx* ctx, int n_extra, const void* const* img1, const void* const* img2,
+                           size_t row_stride_bytes);
+
+/* findCPPMax (image2.cpp:216-308, image-find-cpp.cpp:68-158): product of the n_bands planes of an
+ * fft-shifted correlation raster (host, width*height floats each), then the first maximum above -1
+ * outside a central mask of mask_pct percent of the half sizes (clamped as image2.cpp:256-257);
+ * offsets are relative to the raster centre, *peak is the maximum (-1 when nothing exceeded it). */
+int mis_masked_peak(mis_ctx* ctx, const float* bands, int width, int height, int n_bands, float mask_pct,
+                    int* offset_x, int* offset_y, float* peak);
+
 /* image-fft.cpp:45-105 (CalcFFT): forward 2-D DFT of `batch` real rasters of w x h pixels
  * (contiguous, row stride w), each value divided by sqrt(w*h); out: batch*w*h complex64
  * (interleaved re,im).  Host pointers.  w, h: as for mis_xcorr_tiles. */

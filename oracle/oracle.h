@@ -61,6 +61,16 @@ int orc_find_offset(const void* img1, int w1, int h1, size_t stride1,
                     orc_offset* out,
                     float* surface /* nullable: width*height normalised |c| (image3.cpp:414-416) */,
                     float* dog /* nullable: width*height DoG image (image3.cpp:483) */);
+/* the same with the band loop of image3.cpp:382-418 open (the reference forces n_bands = 1,
+ * image3.cpp:353): the normalised surfaces of the bands are multiplied */
+int orc_find_offset_bands(const void* const* imgs1, int w1, int h1, size_t stride1,
+                          const void* const* imgs2, int w2, int h2, size_t stride2, int dtype, int n_bands,
+                          orc_rect b1, orc_rect b2, int width, int height, int precision,
+                          orc_offset* out, float* surface, float* dog);
+/* findCPPMax (image2.cpp:216-308, image-find-cpp.cpp:68-158): masked first maximum of the band
+ * product of an fft-shifted correlation raster; returns the maximum */
+float orc_masked_peak(const float* bands, int cols, int rows, int n_bands, float mask_pct,
+                      int* offset_x, int* offset_y);
 /* the 151-tap sigma-99 blur alone, OpenCV 2.4 GaussianBlur semantics (image3.cpp:481) */
 void orc_gaussian_blur(const float* src, float* dst, int width, int height, int ksize, double sigma);
 /* image-cross-cor.cpp:104-176: whole-image correlation surface -> floor(norm*255) u8, fft-shifted */

@@ -147,6 +147,44 @@ def find_offset(img1, img2, b1, b2, width, height, precision=0, want_surface=Fal
     return res
 
 
+def find_offset_bands(bands1, bands2, b1, b2, width, height, precision=0, want_surface=False, want_dog=False):
+    """bands1 / bands2: lists of equally shaped rasters (one per band)."""
+    bands1 = [np.ascontiguousarray(b) for b in bands1]
+    bands2 = [np.ascontiguousarray(b) for b in bands2]
+    nb = len(bands1)
+    assert nb == len(bands2) and nb >= 1
+    p1 = (C.c_void_p * nb)(*[b.ctypes.data for b in bands1])
+    p2 = (C.c_void_p * nb)(*[b.ctypes.data for b in bands2])
+    i1, i2 = bands1[0], bands2[0]
+    r1, r2 = Rect(*b1), Rect(*b2)
+    off = Offset()
+    surf = np.empty((height, width), np.float32) if want_surface else None
+    dog = np.empty((height, width), np.float32) if want_dog else None
+    lib().orc_find_offset_bands(p1, i1.shape[1], i1.shape[0], C.c_size_t(i1.strides[0]),
+                                p2, i2.shape[1], i2.shape[0], C.c_size_t(i2.strides[0]),
+                                _dtype_code(i1), nb, r1, r2, width, height, precision, C.byref(off),
+                                _ptr(surf), _ptr(dog))
+    res = {"dx": off.dx, "dy": off.dy, "peak": off.peak, "dog_peak": off.dog_peak}
+    if want_surface:
+        res["surface"] = surf
+    if want_dog:
+        res["dog"] = dog
+    return res
+
+
+def masked_peak(bands, mask_pct):
+    """findCPPMax: bands [n, rows, cols] float32 -> (peak, offset_x, offset_y)."""
+    bands = np.ascontiguousarray(bands, np.float32)
+    if bands.ndim == 2:
+        bands = bands[None]
+    nb, rows, cols = bands.shape
+    ox, oy = C.c_int(0), C.c_int(0)
+    f = lib().orc_masked_peak
+    f.restype = C.c_float
+    peak = f(_ptr(bands), cols, rows, nb, C.c_float(mask_pct), C.byref(ox), C.byref(oy))
+    return float(peak), ox.value, oy.value
+
+
 def gaussian_blur(src, ksize=151, sigma=99.0):
     src = np.ascontiguousarray(src, np.float32)
     dst = np.empty_like(src)

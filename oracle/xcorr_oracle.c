@@ -190,20 +190,29 @@ static int corr_surface(const double* t1, const double* t2, int width, int heigh
     return (fmax == fmin) ? 1 : 0;
 }
 
-/* image3.cpp:346-517 findOffset (n_bands forced to 1, image3.cpp:353) */
-int orc_find_offset(const void* img1, int w1, int h1, size_t stride1,
-                    const void* img2, int w2, int h2, size_t stride2, int dtype,
-                    orc_rect b1, orc_rect b2, int width, int height, int precision,
-                    orc_offset* res, float* surface, float* dog_out)
+/* image3.cpp:346-517 findOffset with the band loop of image3.cpp:382-418 left open: the reference
+ * computes n_bands and then forces it to 1 (image3.cpp:352-353); n_bands == 1 is that behaviour,
+ * n_bands > 1 multiplies the normalised surfaces of the bands (out[i] = out[i] * norm, the
+ * product evaluated in double and narrowed, image3.cpp:414-416). */
+int orc_find_offset_bands(const void* const* imgs1, int w1, int h1, size_t stride1,
+                          const void* const* imgs2, int w2, int h2, size_t stride2, int dtype, int n_bands,
+                          orc_rect b1, orc_rect b2, int width, int height, int precision,
+                          orc_offset* res, float* surface, float* dog_out)
 {
     size_t n = (size_t)width * height;
     double* t1 = (double*)malloc(sizeof(double) * n);
     double* t2 = (double*)malloc(sizeof(double) * n);
     float* out = (float*)malloc(sizeof(float) * n);
-    load_tile(t1, img1, w1, h1, stride1, dtype, b1, width, height);
-    load_tile(t2, img2, w2, h2, stride2, dtype, b2, width, height);
-    corr_surface(t1, t2, width, height, precision, out, NULL, NULL, NULL);
-    free(t1); free(t2);
+    float* band = (float*)malloc(sizeof(float) * n);
+    double* bandd = (double*)malloc(sizeof(double) * n);
+    for (size_t i = 0; i < n; i++) out[i] = 1.0f;                 /* image3.cpp:378-380 */
+    for (int b = 0; b < n_bands; b++) {
+        load_tile(t1, imgs1[b], w1, h1, stride1, dtype, b1, width, height);
+        load_tile(t2, imgs2[b], w2, h2, stride2, dtype, b2, width, height);
+        corr_surface(t1, t2, width, height, precision, band, bandd, NULL, NULL);
+        for (size_t i = 0; i < n; i++) out[i] = (float)((double)out[i] * bandd[i]);
+    }
+    free(t1); free(t2); free(band); free(bandd);
     if (surface) memcpy(surface, out, sizeof(float) * n);
 
     /* image3.cpp:456-483 */
@@ -236,6 +245,53 @@ int orc_find_offset(const void* img1, int w1, int h1, size_t stride1,
     res->peak = max_out; res->dog_peak = max;
     free(imout); free(g1); free(out);
     return 0;
+}
+
+/* image3.cpp:346-517 findOffset as the reference runs it (band 1 only) */
+int orc_find_offset(const void* img1, int w1, int h1, size_t stride1,
+                    const void* img2, int w2, int h2, size_t stride2, int dtype,
+                    orc_rect b1, orc_rect b2, int width, int height, int precision,
+                    orc_offset* res, float* surface, float* dog_out)
+{
+    return orc_find_offset_bands(&img1, w1, h1, stride1, &img2, w2, h2, stride2, dtype, 1,
+                                 b1, b2, width, height, precision, res, surface, dog_out);
+}
+
+/* findCPPMax (image2.cpp:216-308, image-find-cpp.cpp:68-158): product of the bands of an
+ * fft-shifted correlation raster, first strict maximum outside a central mask of mask_pct percent
+ * of the half sizes; offsets are relative to the raster centre.  bands: n_bands planes of
+ * rows*cols floats. */
+float orc_masked_peak(const float* bands, int cols, int rows, int n_bands, float mask_pct,
+                      int* offset_x, int* offset_y)
+{
+    size_t px_count = (size_t)rows * cols;
+    float* img = (float*)malloc(sizeof(float) * px_count);
+    memcpy(img, bands, sizeof(float) * px_count);
+    for (int band = 1; band < n_bands; band++)
+        for (size_t i = 0; i < px_count; i++) img[i] = img[i] * bands[(size_t)band * px_count + i];
+    const int pp_row = rows / 2, pp_col = cols / 2;
+    const int rows2 = pp_row * 2, cols2 = pp_col * 2;
+    if (mask_pct > 99) mask_pct = 99;
+    if (mask_pct <= 1) mask_pct = 0;
+    /* int * float / int: float arithmetic, truncated on assignment (image2.cpp:259-263) */
+    const int mask_min_row = pp_row - (pp_row * mask_pct / 100);
+    const int mask_max_row = pp_row + (pp_row * mask_pct / 100);
+    const int mask_min_col = pp_col - (pp_col * mask_pct / 100);
+    const int mask_max_col = pp_col + (pp_col * mask_pct / 100);
+    float max = -1;
+    int max_col = 0, max_row = 0;
+    for (int row = 0; row < rows2; row++) {
+        int central = (row >= mask_min_row) && (row < mask_max_row);
+        for (int col = 0; col < cols2; col++) {
+            if (central && col >= mask_min_col && col < mask_max_col) continue;
+            float v = img[(size_t)row * cols + col];
+            if (v > max) { max = v; max_col = col; max_row = row; }
+        }
+    }
+    *offset_x = max_col - pp_col;
+    *offset_y = max_row - pp_row;
+    free(img);
+    return max;
 }
 
 /* image-cross-cor.cpp:104-176 for one band, both rasters the size of the output

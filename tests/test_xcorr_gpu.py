@@ -171,3 +171,49 @@ def test_xcorr_surface_u8_odd_size(ctx):
     want = oracle.xcorr_surface_u8(img1, img2, precision=1).astype(np.int32)
     d = np.abs(got - want)
     assert d.max() <= 1 and (d > 0).mean() <= 0.02
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (100, 60)])
+def test_multi_band_product(ctx, w, h):
+    """Three bands: the normalised surfaces are multiplied (image3.cpp:382-418 with n_bands not
+    forced to 1), on the power-of-two path and on the general one."""
+    pairs = [_pair(h, w, 6, -3, 40 + b) for b in range(3)]
+    b1, b2 = [p[0] for p in pairs], [p[1] for p in pairs]
+    ctx.upload_pair(b1[0], b2[0])
+    ctx.upload_extra_bands(b1[1:], b2[1:])
+    peak, ox, oy = ctx.find_offset((0, 0, w, h), (0, 0, w, h), w, h)
+    surf, dog = ctx.tile_surfaces((0, 0, w, h), (0, 0, w, h), w, h)
+    ref = oracle.find_offset_bands(b1, b2, (0, 0, w, h), (0, 0, w, h), w, h, precision=1, want_surface=True, want_dog=True)
+    assert (ox, oy) == (ref["dx"], ref["dy"]) == (6, -3)
+    assert abs(peak - ref["peak"]) <= 1e-4 * max(abs(ref["peak"]), 1e-3) + 1e-5
+    assert np.abs(surf - ref["surface"]).max() <= 5e-5
+    assert np.abs(dog - ref["dog"]).max() <= 1e-4
+    single = oracle.find_offset(b1[0], b2[0], (0, 0, w, h), (0, 0, w, h), w, h, precision=1, want_surface=True)
+    assert np.abs(surf - single["surface"]).max() > 1e-3        # the product differs from band 1 alone
+    # binding a new pair drops the extra bands
+    ctx.upload_pair(b1[0], b2[0])
+    surf1, _ = ctx.tile_surfaces((0, 0, w, h), (0, 0, w, h), w, h)
+    assert np.abs(surf1 - single["surface"]).max() <= 3e-5
+
+
+@pytest.mark.parametrize("rows,cols,nb,pct", [(64, 96, 1, 0), (64, 96, 2, 30), (75, 101, 3, 50), (40, 40, 1, 99.5),
+                                              (40, 40, 1, 1.0), (33, 64, 2, 150)])
+def test_masked_peak(ctx, rows, cols, nb, pct):
+    """findCPPMax (image2.cpp:216-308): band product and first maximum outside the central mask."""
+    rng = np.random.default_rng(rows + cols + nb)
+    bands = rng.random((nb, rows, cols)).astype(np.float32)
+    bands[:, rows // 2, cols // 2] = 5.0                          # a central peak the mask must hide
+    bands[:, 3, 7] = 2.0
+    bands[:, rows // 2 - 1, 5] = 2.0                              # equal maxima: the first in row-major order wins
+    got = ctx.masked_peak(bands, pct)
+    want = oracle.masked_peak(bands, pct)
+    assert got == want
+    if pct in (30, 50):
+        assert (got[1], got[2]) == (7 - cols // 2, 3 - rows // 2)
+    elif pct <= 1:
+        assert (got[1], got[2]) == (0, 0)
+
+
+def test_masked_peak_nothing_above_minus_one(ctx):
+    bands = np.full((1, 16, 16), -2.0, np.float32)
+    assert ctx.masked_peak(bands, 10) == oracle.masked_peak(bands, 10) == (-1.0, -8, -8)
