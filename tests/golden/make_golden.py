@@ -285,7 +285,70 @@ def main():
         tri["A2_%d" % i], tri["R2_%d" % i], tri["T2_%d" % i] = c2
         tri["xyz_%d" % i] = np.array([calculate_xyz_numpy(c1, c2, *p) for p in pts], np.float32)
     np.savez_compressed(os.path.join(HERE, "tri_cases.npz"), **tri)
+    main_general()
     print("golden vectors written to", HERE)
+
+
+def masked_peak_numpy(bands, mask_pct):
+    """findCPPMax (image2.cpp:216-308) with numpy float32 scalars."""
+    img = bands[0].astype(np.float32).copy()
+    for b in bands[1:]:
+        img = img * b.astype(np.float32)
+    rows, cols = img.shape
+    pp_row, pp_col = rows // 2, cols // 2
+    pct = F(mask_pct)
+    if pct > 99:
+        pct = F(99)
+    if pct <= 1:
+        pct = F(0)
+    r0 = int(F(pp_row) - F(pp_row) * pct / F(100)); r1 = int(F(pp_row) + F(pp_row) * pct / F(100))
+    c0 = int(F(pp_col) - F(pp_col) * pct / F(100)); c1 = int(F(pp_col) + F(pp_col) * pct / F(100))
+    sub = img[:pp_row * 2, :pp_col * 2].copy()
+    sub[max(r0, 0):max(r1, 0), max(c0, 0):max(c1, 0)] = -np.inf
+    k = int(np.argmax(sub))
+    row, col = divmod(k, pp_col * 2)
+    if not sub[row, col] > -1:
+        return np.float32(-1), -pp_col, -pp_row
+    return np.float32(sub[row, col]), col - pp_col, row - pp_row
+
+
+def main_general():
+    """Sizes that are not powers of two, the band product and the masked peak search."""
+    rng = np.random.default_rng(20240612)
+    xc = {}
+    for name, (w, h, dx, dy) in {"g48x40": (48, 40, 5, -3), "g45x31": (45, 31, -4, 2), "g64x20": (64, 20, 7, 1)}.items():
+        big = synth.texture(h + 40, w + 40, int(rng.integers(1 << 30)))
+        img2 = np.ascontiguousarray(big[20:20 + h, 20:20 + w])
+        img1 = np.ascontiguousarray(big[20 - dy:20 - dy + h, 20 - dx:20 - dx + w])
+        r = find_offset_numpy(img1, img2, (0, 0, w, h), (0, 0, w, h), w, h)
+        xc[name] = dict(img1=img1, img2=img2, w=w, h=h, **r)
+    np.savez_compressed(os.path.join(HERE, "xcorr_general_cases.npz"),
+                        **{"%s__%s" % (n, k): np.asarray(v) for n, c in xc.items() for k, v in c.items()})
+
+    # band product (image3.cpp:382-418 with the band loop open): product of the normalised surfaces
+    w = h = 32
+    b1, b2, prod = [], [], np.ones((h, w), np.float32)
+    for b in range(3):
+        big = synth.texture(h + 20, w + 20, int(rng.integers(1 << 30)))
+        i2 = np.ascontiguousarray(big[10:10 + h, 10:10 + w]); i1 = np.ascontiguousarray(big[10 + 2:10 + 2 + h, 10 - 3:10 - 3 + w])
+        b1.append(i1); b2.append(i2)
+        r = find_offset_numpy(i1, i2, (0, 0, w, h), (0, 0, w, h), w, h)
+        prod = (prod.astype(np.float64) * r["surface"].astype(np.float64)).astype(np.float32)
+    imout = prod.copy()
+    dog = imout - gaussian_blur_numpy(imout)
+    k = int(np.argmax(dog)); row, col = divmod(k, w)
+    peak = prod[row, col]
+    col = col - w if col > w // 2 else col
+    row = row - h if row > h // 2 else row
+    mp = {}
+    for i, (rows, cols, nb, pct) in enumerate([(20, 30, 1, 0.0), (20, 30, 2, 40.0), (21, 33, 3, 60.0), (16, 16, 1, 120.0)]):
+        bands = rng.random((nb, rows, cols)).astype(np.float32)
+        bands[:, rows // 2, cols // 2] = 3.0
+        pk, ox, oy = masked_peak_numpy(bands, pct)
+        mp["mp%d__bands" % i] = bands; mp["mp%d__pct" % i] = np.float32(pct)
+        mp["mp%d__result" % i] = np.array([pk, ox, oy], np.float64)
+    np.savez_compressed(os.path.join(HERE, "bands_cases.npz"), bands1=np.stack(b1), bands2=np.stack(b2),
+                        surface=prod, dog=dog.astype(np.float32), dx=col, dy=row, peak=np.float32(peak), **mp)
 
 
 if __name__ == "__main__":

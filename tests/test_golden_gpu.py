@@ -60,3 +60,33 @@ def test_triangulation_golden_bit_exact(ctx):
         c2 = mistereo.make_camera(z["A2_%d" % i], z["R2_%d" % i], z["T2_%d" % i])
         got = ctx.calculate_xyz(c1, c2, z["pts"])
         assert np.array_equal(got.view(np.uint32), z["xyz_%d" % i].view(np.uint32))
+
+
+@pytest.mark.parametrize("case", ["g48x40", "g45x31", "g64x20"])
+def test_find_offset_golden_general_sizes(ctx, case):
+    c = load_cases("xcorr_general_cases.npz")[case]
+    w, h = int(c["w"]), int(c["h"])
+    ctx.upload_pair(c["img1"], c["img2"])
+    peak, dx, dy = ctx.find_offset((0, 0, w, h), (0, 0, w, h), w, h)
+    assert (dx, dy) == (int(c["dx"]), int(c["dy"]))
+    assert abs(peak - float(c["peak"])) <= 1e-4 * max(abs(float(c["peak"])), 1e-3) + 1e-5
+    surf, dog = ctx.tile_surfaces((0, 0, w, h), (0, 0, w, h), w, h)
+    assert np.abs(surf - c["surface"]).max() <= 3e-5
+    assert np.abs(dog - c["dog"]).max() <= 1e-4
+
+
+def test_band_product_and_masked_peak_golden(ctx):
+    z = np.load(os.path.join(GOLDEN, "bands_cases.npz"))
+    b1, b2 = list(z["bands1"]), list(z["bands2"])
+    ctx.upload_pair(b1[0], b2[0])
+    ctx.upload_extra_bands(b1[1:], b2[1:])
+    peak, dx, dy = ctx.find_offset((0, 0, 32, 32), (0, 0, 32, 32), 32, 32)
+    surf, dog = ctx.tile_surfaces((0, 0, 32, 32), (0, 0, 32, 32), 32, 32)
+    assert (dx, dy) == (int(z["dx"]), int(z["dy"]))
+    assert abs(peak - float(z["peak"])) <= 1e-4 * max(abs(float(z["peak"])), 1e-3) + 1e-5
+    assert np.abs(surf - z["surface"]).max() <= 5e-5
+    assert np.abs(dog - z["dog"]).max() <= 1e-4
+    for i in range(4):
+        pk, ox, oy = ctx.masked_peak(z["mp%d__bands" % i], float(z["mp%d__pct" % i]))
+        want = z["mp%d__result" % i]
+        assert (np.float32(pk), ox, oy) == (np.float32(want[0]), int(want[1]), int(want[2]))

@@ -108,3 +108,29 @@ def test_disparity_map_recursion_counts():
     assert calls == 21 and len(leaves) == 16
     assert all(l[4] == 0 and l[5] == 0 for l in leaves)
     assert sorted((l[0], l[1]) for l in leaves) == sorted((i, j) for j in range(0, 256, 64) for i in range(0, 256, 64))
+
+
+@pytest.mark.parametrize("case", ["g48x40", "g45x31", "g64x20"])
+def test_find_offset_oracle_general_sizes(case):
+    c = load_cases("xcorr_general_cases.npz")[case]
+    w, h = int(c["w"]), int(c["h"])
+    o = oracle.find_offset(c["img1"], c["img2"], (0, 0, w, h), (0, 0, w, h), w, h, precision=1,
+                           want_surface=True, want_dog=True)
+    assert (o["dx"], o["dy"]) == (int(c["dx"]), int(c["dy"]))
+    assert abs(o["peak"] - float(c["peak"])) <= 2e-6
+    assert np.abs(o["surface"] - c["surface"]).max() <= 2e-6
+    assert np.abs(o["dog"] - c["dog"]).max() <= 1e-5
+
+
+def test_band_product_and_masked_peak_oracle():
+    z = np.load(os.path.join(GOLDEN, "bands_cases.npz"))
+    b1, b2 = list(z["bands1"]), list(z["bands2"])
+    o = oracle.find_offset_bands(b1, b2, (0, 0, 32, 32), (0, 0, 32, 32), 32, 32, precision=1,
+                                 want_surface=True, want_dog=True)
+    assert (o["dx"], o["dy"]) == (int(z["dx"]), int(z["dy"]))
+    assert np.abs(o["surface"] - z["surface"]).max() <= 5e-6
+    assert np.abs(o["dog"] - z["dog"]).max() <= 2e-5
+    for i in range(4):
+        pk, ox, oy = oracle.masked_peak(z["mp%d__bands" % i], float(z["mp%d__pct" % i]))
+        want = z["mp%d__result" % i]
+        assert (np.float32(pk), ox, oy) == (np.float32(want[0]), int(want[1]), int(want[2]))
