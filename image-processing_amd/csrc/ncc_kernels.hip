@@ -638,7 +638,6 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
                         ncc_pin_s(av[set][e]);
                         C[k] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, av[set][e]),
                                                       __builtin_bit_cast(half2_t, bv[set][e]), C[k], false);
-                        ncc_pin(C[k]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

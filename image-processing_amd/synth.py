@@ -63,7 +63,7 @@ def shift_right_image_subpixel(left, d):
     b = left[:, np.clip(x0 + 1, 0, w - 1)].astype(np.float64)
     out = a * (1 - f)[None, :] + b * f[None, :]
     info = np.iinfo(left.dtype)
-    return np.clip(np.rint(out), info.min, info.max).astype(left.dtype)
+    return np.ascontiguousarray(np.clip(np.rint(out), info.min, info.max).astype(left.dtype))
 
 
 def planar_disparity(h, w, dlo, dhi, block, seed):

@@ -1,6 +1,7 @@
-"""Timing of the 16-bit dense NCC (31x31 window, +-512 search) followed by triangulation of every
-pixel's disparity to XYZ, device resident.  Usage: python tools/bench_ncc16.py [size] [steps]"""
-import os, sys, time
+"""BASELINE config[4]: 16-bit imagery, 31x31 window, +-512 px search, subpixel peak and triangulation
+of every matched pixel to XYZ, device resident.  Usage: python tools/bench_ncc16.py [size] [steps]
+Prints one JSON line (not the headline metric: bench.py reports that)."""
+import json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R + '/image-processing_amd']
 import numpy as np, torch, mistereo, synth
@@ -8,18 +9,38 @@ import numpy as np, torch, mistereo, synth
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 window, dmin, dmax = 31, -512, 512
+true_d = 137.375                                 # fractional shift: the subpixel truth
 ctx = mistereo.Context(0)
-left = synth.texture(size, size, 5, np.uint16)
-right = synth.shift_right_image(left, synth.planar_disparity(size, size, -400, 400, 256, 7), fill_seed=9)
-tl, tr = torch.from_numpy(left.view(np.int16)).cuda().view(torch.uint16), torch.from_numpy(right.view(np.int16)).cuda().view(torch.uint16)
+left = synth.texture(size, size, 0xC0FFEE + 4, np.uint16)
+right = synth.shift_right_image_subpixel(left, true_d)
+tl = torch.from_numpy(left.view(np.int16)).cuda().view(torch.uint16)
+tr = torch.from_numpy(right.view(np.int16)).cuda().view(torch.uint16)
 disp = torch.empty((size, size), dtype=torch.float32, device="cuda")
 peak = torch.empty_like(disp)
+xyz = torch.empty((size, size, 3), dtype=torch.float32, device="cuda")
+A = [[10000, 0, size / 2], [0, 10000, size / 2], [0, 0, 1]]       # f = 10000 px, height 3000 m, baseline 900 m, R = I
+c1 = mistereo.make_camera(A, np.eye(3), [0, 0, -3000])
+c2 = mistereo.make_camera(A, np.eye(3), [-900, 0, -3000])
 ctx.profile(True)
+times = []
 for it in range(steps + 1):
     ctx.bind_pair_torch(tl, tr)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ctx.ncc_dense_torch(window, dmin, dmax, disp, peak)
+    matched = ctx.triangulate_disparity_torch(c1, c2, disp, peak, 0.75, xyz)
     ctx.synchronize(); t1 = time.perf_counter()
     if it:
-        print("step %d: %.2f ms  %.1f Gpx*disp/s" % (it, (t1 - t0) * 1e3, size * size * (dmax - dmin + 1) / (t1 - t0) / 1e9), flush=True)
-print("profile (tables, argmax, refine ms, calls):", ctx.profile_read())
+        times.append(t1 - t0)
+dt = min(times)
+tables, argmax, refine, calls = ctx.profile_read()
+r = window // 2
+inner = disp[r:-r, 600:-600]
+ok = inner > -30000
+err = (inner[ok] - true_d).abs()
+print(json.dumps({
+    "metric": "NCC throughput (16-bit, 31x31, +-512, subpixel, XYZ)", "value": round(size * size * (dmax - dmin + 1) / dt / 1e9, 1),
+    "unit": "Gpx*disp/s", "ms_per_step": round(dt * 1e3, 2), "size": size,
+    "matched_points_per_s": round(matched / dt, 1), "matched_fraction": round(matched / size / size, 4),
+    "subpixel_mean_abs_err_px": round(float(err.mean()), 5), "subpixel_p99_abs_err_px": round(float(err.quantile(0.99)) if err.numel() < 16e6 else float(err[:16000000].quantile(0.99)), 5),
+    "kernel_ms": {"tables": round(tables / calls, 2), "argmax16": round(argmax / calls, 2), "refine16": round(refine / calls, 2)},
+}), flush=True)

@@ -1,0 +1,18 @@
+"""Host-buffer (PCIe-inclusive) rate of the dense NCC at BASELINE config[1]: mis_upload_pair from
+host rasters, mis_ncc_dense with host outputs.  Reported in DESIGN.md, never as bench.py's value."""
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [R + '/image-processing_amd']
+import numpy as np, mistereo, synth
+size, D, win = 8192, 256, 21
+ctx = mistereo.Context(0)
+left = synth.texture(size, size, 5)
+right = synth.shift_right_image(left, synth.planar_disparity(size, size, -200, 200, 64, 7), fill_seed=9)
+for it in range(3):
+    t0 = time.perf_counter()
+    ctx.upload_pair(left, right)
+    t1 = time.perf_counter()
+    out = ctx.ncc_dense(win, -D, D, want_idisp=False)
+    t2 = time.perf_counter()
+    print("upload %.1f ms, ncc_dense with host outputs %.1f ms, total %.1f ms -> %.1f Gpx*disp/s" % (
+        (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3, size * size * (2 * D + 1) / (t2 - t0) / 1e9), flush=True)
