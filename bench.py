@@ -41,13 +41,13 @@ def parse():
     return ap.parse_args()
 
 
-def load_traffic_note(kernel_name):
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc run, if any."""
+def load_traffic_note(kernel_name, field="bytes"):
+    """HBM bytes per launch (or another field) of the dominant kernel from a committed rocprofv3 --pmc run."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             entry = json.load(f).get(kernel_name)
-        return entry.get("bytes") if isinstance(entry, dict) else entry
+        return entry.get(field) if isinstance(entry, dict) else (entry if field == "bytes" else None)
     except Exception:
         return None
 
@@ -211,6 +211,7 @@ def main():
                          "tables_ms": round(pre_ms / max(calls, 1), 4),
                          "refine_ms": round(refine_ms / max(calls, 1), 4),
                          "algorithmic_bytes": alg_bytes,
+                         "valu_busy_frac_pmc": load_traffic_note(kname, "valu_busy"),
                          "note": "sliding-window correlation: compulsory HBM traffic is 10 B/px whatever the search "
                                  "range, the kernel is bound by vector ALU / LDS issue, not by HBM"},
         }
