@@ -137,7 +137,8 @@ def main():
     def step(i):
         b = i % nbuf
         if pipe:
-            pipe.reuse(b)              # the buffer's previous gather has drained
+            pipe.reuse(b)              # the buffer's previous gather has drained (a wait on torch's current stream) ...
+            stream.wait_stream(torch.cuda.current_stream())   # ... and the library's stream must honour it too
         with torch.cuda.stream(stream):
             # re-binding invalidates the context's per-pair tables: every step redoes all the work
             ctx.bind_pair_torch(left, right)

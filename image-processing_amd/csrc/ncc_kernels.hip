@@ -33,8 +33,6 @@ struct NccWs {
     uint32_t* Rpack = nullptr;  // half2( R'(x,y), R'(x,y-W) )
     float* Rsr = nullptr;       // S_R (window sum of R')
     float* Rir = nullptr;       // 1/sqrt(sum (R-mean)^2), 0 when flat, NaN where the window does not fit
-    int32_t* hs1 = nullptr;     // horizontal window sums (scratch)
-    int32_t* hs2 = nullptr;
     uint32_t* VL = nullptr;     // [ceil(H/4)][pitch]: 4 vertically adjacent pixels, (p-128) as int8 each
     uint32_t* VR = nullptr;
     float* keys = nullptr;      // [chunks][H][W] best key per pixel and chunk of 64 disparities
@@ -49,112 +47,109 @@ void mis_ncc_release(mis_ctx* ctx)
 {
     NccWs* w = ctx->ncc;
     if (!w) return;
-    void* bufs[] = { w->Lpack, w->negc, w->negg, w->iL, w->Rpack, w->Rsr, w->Rir, w->hs1, w->hs2, w->VL, w->VR, w->keys };
+    void* bufs[] = { w->Lpack, w->negc, w->negg, w->iL, w->Rpack, w->Rsr, w->Rir, w->VL, w->VR, w->keys };
     for (void* b : bufs) if (b) (void)hipFree(b);
     delete w;
     ctx->ncc = nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pre-pass 1: horizontal window sums of p' = p - 128 and p'^2, one thread per pixel.
+// Pre-pass 1: window statistics and the packed row pairs, one pass over the raster.
+// A workgroup owns 256 columns and a band of rows.  It walks down the band (plus r rows above and
+// below): each row is staged in LDS (p' = p - 128), every thread sums its column's horizontal
+// window of p' and p'^2, keeps the last 2r+1 such row sums in an LDS ring (a thread only touches
+// its own ring column) and slides the vertical window over them.  |sum p'| < 2^12 and
+// sum p'^2 < 2^19 for windows up to 31, so a ring entry is one 32-bit word.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void ncc_hsum_kernel(const T* __restrict__ img, size_t stride_px,
-                                                       int W, int H, int r, int pitch,
-                                                       int32_t* __restrict__ hs1, int32_t* __restrict__ hs2)
-{
-    __shared__ int tile[256 + 2 * 16];
-    const int y = blockIdx.y;
-    const int x0 = blockIdx.x * 256;
-    const T* row = img + (size_t)y * stride_px;
-    for (int i = threadIdx.x; i < 256 + 2 * r; i += 256) {
-        int x = x0 - r + i;
-        tile[i] = (x >= 0 && x < W) ? (int)row[x] - 128 : 0;
-    }
-    __syncthreads();
-    int x = x0 + threadIdx.x;
-    if (x >= pitch) return;
-    int s1 = 0, s2 = 0;
-    for (int i = 0; i <= 2 * r; i++) { int v = tile[threadIdx.x + i]; s1 += v; s2 += v * v; }
-    hs1[(size_t)y * pitch + x] = s1;
-    hs2[(size_t)y * pitch + x] = s2;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Pre-pass 2: vertical sums -> window statistics, and the packed row pairs.
-// ---------------------------------------------------------------------------------------------
-// One thread per column walks down a band of rows, sliding the vertical window over the
-// horizontal sums (two loads in, two loads out per row).
 #define NCC_STATS_BAND 128
 template <typename T, bool LEFT>
-__global__ __launch_bounds__(256) void ncc_stats_kernel(const T* __restrict__ img, size_t stride_px,
-                                                        int W, int H, int r, int pitch,
-                                                        const int32_t* __restrict__ hs1,
-                                                        const int32_t* __restrict__ hs2,
-                                                        uint32_t* __restrict__ pack,
-                                                        float* __restrict__ o0,   // LEFT: negc   RIGHT: S_R
-                                                        float* __restrict__ o1,   // LEFT: negg   RIGHT: iR
-                                                        float* __restrict__ o2)   // LEFT: iL
+__global__ __launch_bounds__(256) void ncc_tables_kernel(const T* __restrict__ img, size_t stride_px,
+                                                         int W, int H, int r, int pitch,
+                                                         uint32_t* __restrict__ pack,
+                                                         float* __restrict__ o0,   // LEFT: negc   RIGHT: S_R
+                                                         float* __restrict__ o1,   // LEFT: negg   RIGHT: iR
+                                                         float* __restrict__ o2)   // LEFT: iL
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= pitch) return;
+    __shared__ int rowbuf[2][256 + 32];
+    __shared__ uint32_t ring[31][256];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * 256, x = x0 + tid;
     const int y0 = blockIdx.y * NCC_STATS_BAND;
     const int y1 = min(y0 + NCC_STATS_BAND, H);
     const int Wn = 2 * r + 1;
     const long long N = (long long)Wn * Wn;
     const bool colok = (x >= r && x < W - r);
-    long long s1 = 0, s2 = 0;           // window sums for the rows y-r .. y+r
-    bool have = false;
-    for (int y = y0; y < y1; y++) {
-        const size_t o = (size_t)y * pitch + x;
-        // packed pair: this row and the row Wn above
-        float a = 0.f, b = 0.f;
-        if (x < W) {
-            a = (float)((int)img[(size_t)y * stride_px + x] - 128);
-            if (y - Wn >= 0) b = (float)((int)img[(size_t)(y - Wn) * stride_px + x] - 128);
+    int s1 = 0, s2 = 0;                 // vertical sums of the ring: rows yy-2r .. yy
+    int slot = 0;
+    // a row is fetched into registers one iteration ahead and published to LDS after the arithmetic
+    auto fetch = [&](int yy, int i) -> int {
+        const int xs = x0 - r + i;
+        return (yy >= 0 && yy < H && xs >= 0 && xs < W && i < 256 + 2 * r) ? (int)img[(size_t)yy * stride_px + xs] - 128 : 0;
+    };
+    rowbuf[0][tid] = fetch(y0 - r, tid);
+    if (tid < 32) rowbuf[0][256 + tid] = fetch(y0 - r, 256 + tid);
+    __syncthreads();
+    for (int yy = y0 - r; yy < y1 + r; yy++) {
+        const int buf = (yy - (y0 - r)) & 1;
+        const bool more = (yy + 1 < y1 + r);
+        int nxt0 = 0, nxt1 = 0;
+        if (more) { nxt0 = fetch(yy + 1, tid); if (tid < 32) nxt1 = fetch(yy + 1, 256 + tid); }
+        int h1 = 0, h2 = 0;
+        for (int i = 0; i <= 2 * r; i++) { const int v = rowbuf[buf][tid + i]; h1 += v; h2 += v * v; }
+        if (yy - (y0 - r) >= Wn) {      // the ring is full: drop the row that leaves the window
+            const uint32_t old = ring[slot][tid];
+            s1 -= (int)(old >> 19) - 4096;
+            s2 -= (int)(old & 0x7FFFFu);
         }
-        half2_t h;
-        h.x = (_Float16)a;
-        h.y = (_Float16)(LEFT ? -b : b);
-        pack[o] = __builtin_bit_cast(uint32_t, h);
+        ring[slot][tid] = ((uint32_t)(h1 + 4096) << 19) | (uint32_t)h2;
+        slot = (slot + 1 == Wn) ? 0 : slot + 1;
+        s1 += h1; s2 += h2;
 
-        const bool rowok = (y >= r && y < H - r);
-        float v0 = 0.f, v1 = LEFT ? 0.f : (colok ? 0.f : __builtin_nanf("")), v2 = 0.f;
-        if (colok && rowok) {
-            if (!have) {
-                s1 = 0; s2 = 0;
-                for (int j = -r; j <= r; j++) {
-                    s1 += hs1[(size_t)(y + j) * pitch + x];   // hs*[..][x]: horizontal window centred at x
-                    s2 += hs2[(size_t)(y + j) * pitch + x];
+        const int y = yy - r;           // the window centred at y is complete now
+        if (y >= y0 && x < pitch) {
+            const size_t o = (size_t)y * pitch + x;
+            // packed pair: this row and the row Wn above
+            float a = 0.f, b = 0.f;
+            if (x < W) {
+                a = (float)((int)img[(size_t)y * stride_px + x] - 128);
+                if (y - Wn >= 0) b = (float)((int)img[(size_t)(y - Wn) * stride_px + x] - 128);
+            }
+            half2_t h;
+            h.x = (_Float16)a;
+            h.y = (_Float16)(LEFT ? -b : b);
+            pack[o] = __builtin_bit_cast(uint32_t, h);
+
+            const bool rowok = (y >= r && y < H - r);
+            float v0 = 0.f, v1 = LEFT ? 0.f : (colok ? 0.f : __builtin_nanf("")), v2 = 0.f;
+            if (colok && rowok) {
+                const long long var = N * (long long)s2 - (long long)s1 * s1;   // N * sum (p-mean)^2, exact
+                // 1/sigma to float accuracy (a few ulp): scores only need 1e-7 relative
+                const float inv = var > 0 ? sqrtf((float)N / (float)var) : 0.f;
+                if (LEFT) {
+                    // c: the integer nearest to s1/N (N is odd, so there are no ties; float division is
+                    // accurate enough to pick it, and the remainder below is exact whatever c is)
+                    const int c = (int)__builtin_rintf((float)s1 / (float)N);
+                    const int rem = s1 - (int)N * c;
+                    v0 = -(float)c;
+                    v1 = -((float)rem / (float)N);
+                    v2 = inv;
+                } else {
+                    v0 = (float)s1;
+                    v1 = inv;
                 }
-                have = true;
-            } else {
-                s1 += hs1[(size_t)(y + r) * pitch + x] - hs1[(size_t)(y - r - 1) * pitch + x];
-                s2 += hs2[(size_t)(y + r) * pitch + x] - hs2[(size_t)(y - r - 1) * pitch + x];
             }
-            const long long var = N * s2 - s1 * s1;            // N * sum (p-mean)^2, exact
-            const float inv = var > 0 ? (float)sqrt((double)N / (double)var) : 0.f;
             if (LEFT) {
-                long long c = (2 * s1 + N) / (2 * N);          // round(s1/N) for s1 >= 0 ...
-                if (2 * s1 + N < 0) c = -((-(2 * s1 + N) + 2 * N - 1) / (2 * N));   // ... floor for negatives
-                const long long rem = s1 - N * c;
-                v0 = -(float)c;
-                v1 = -(float)((double)rem / (double)N);
-                v2 = inv;
+                // left-image tables are stored shifted left by r columns (entry x-r describes the window
+                // centred at x), so that a strip's first output column x0 = r + 64*strip lands on a
+                // 256-byte boundary for the scalar loads of the correlation kernels
+                if (x >= r) { o0[o - r] = v0; o1[o - r] = v1; o2[o - r] = v2; }
             } else {
-                v0 = (float)s1;
-                v1 = inv;
+                o0[o] = v0;
+                o1[o] = v1;
             }
         }
-        if (LEFT) {
-            // left-image tables are stored shifted left by r columns (entry x-r describes the window
-            // centred at x), so that a strip's first output column x0 = r + 64*strip lands on a
-            // 256-byte boundary for the scalar loads of the correlation kernels
-            if (x >= r) { o0[o - r] = v0; o1[o - r] = v1; o2[o - r] = v2; }
-        } else {
-            o0[o] = v0;
-            o1[o] = v1;
-        }
+        if (more) { rowbuf[buf ^ 1][tid] = nxt0; if (tid < 32) rowbuf[buf ^ 1][256 + tid] = nxt1; }
+        __syncthreads();                // the next row is staged, this row's buffer may be overwritten
     }
 }
 
@@ -851,7 +846,7 @@ static int ncc_prepare(mis_ctx* ctx, int window)
     const size_t npx = (size_t)pitch * H;
     if (w->cap_px < npx) {
         void** bufs[] = { (void**)&w->Lpack, (void**)&w->negc, (void**)&w->negg, (void**)&w->iL,
-                          (void**)&w->Rpack, (void**)&w->Rsr, (void**)&w->Rir, (void**)&w->hs1, (void**)&w->hs2,
+                          (void**)&w->Rpack, (void**)&w->Rsr, (void**)&w->Rir,
                           (void**)&w->VL, (void**)&w->VR };
         for (void** b : bufs) {
             if (*b) { MIS_HIP(ctx, hipFree(*b)); *b = nullptr; }
@@ -864,20 +859,19 @@ static int ncc_prepare(mis_ctx* ctx, int window)
     if (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H)
         return MIS_OK;
     w->pitch = pitch; w->rows = H;
-    dim3 grid((pitch + 255) / 256, H), block(256);
+    dim3 block(256);
     dim3 sgrid((pitch + 255) / 256, (H + NCC_STATS_BAND - 1) / NCC_STATS_BAND);
     hipStream_t s = ctx->stream;
     for (int side = 0; side < 2; side++) {
         const void* img = ctx->img[side];
         if (ctx->dtype == MIS_U8) {
             const uint8_t* p = (const uint8_t*)img;
-            hipLaunchKernelGGL(ncc_hsum_kernel<uint8_t>, grid, block, 0, s, p, ctx->stride, W, H, r, pitch, w->hs1, w->hs2);
             if (side == 0)
-                hipLaunchKernelGGL((ncc_stats_kernel<uint8_t, true>), sgrid, block, 0, s, p, ctx->stride, W, H, r, pitch,
-                                   w->hs1, w->hs2, w->Lpack, w->negc, w->negg, w->iL);
+                hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, true>), sgrid, block, 0, s, p, ctx->stride, W, H, r, pitch,
+                                   w->Lpack, w->negc, w->negg, w->iL);
             else
-                hipLaunchKernelGGL((ncc_stats_kernel<uint8_t, false>), sgrid, block, 0, s, p, ctx->stride, W, H, r, pitch,
-                                   w->hs1, w->hs2, w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
+                hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, false>), sgrid, block, 0, s, p, ctx->stride, W, H, r, pitch,
+                                   w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
             hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, dim3((pitch + 255) / 256, (H + 3) / 4), block, 0, s, p, ctx->stride,
                                W, H, pitch, side == 0 ? w->VL : w->VR);
         } else {
