@@ -558,28 +558,32 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
     // right-image row -> LDS (this wavefront's columns only); element i <-> raster column xr0 + i
     constexpr int NSTG = (SEG + 63) / 64;      // staged elements per lane
     uint32_t nbp[NSTG]; float nsr[NSTG], nir[NSTG];
-    auto fetch = [&](int ynew, int yout, bool stats, bool warm) {
+    // fetch only issues the loads (uniform row base + 32-bit lane offset); nothing touches the loaded
+    // registers before publish, a whole row of arithmetic later, so the memory latency is hidden
+    auto fetch = [&](int ynew, int yout, bool stats) {
+        const uint32_t* rp = gRpack + (size_t)ynew * P;
+        const float* sp = gRsr + (size_t)(stats ? yout : 0) * P;
+        const float* ip = gRir + (size_t)(stats ? yout : 0) * P;
 #pragma unroll
         for (int q = 0; q < NSTG; q++) {
             const int i = lane + 64 * q;
-            const int xr = xr0 + i;
-            const bool in = (xr >= 0 && xr < a.W && i < SEG);
-            uint32_t bp = in ? gRpack[(size_t)ynew * P + xr] : 0u;
-            if (warm) bp &= 0x0000FFFFu;            // warm-up rows: nothing leaves the window yet
-            nbp[q] = bp;
-            nsr[q] = (stats && in) ? gRsr[(size_t)yout * P + xr] : 0.f;
-            nir[q] = stats ? (in ? gRir[(size_t)yout * P + xr] : __builtin_nanf("")) : 0.f;
+            const unsigned xr = (unsigned)(xr0 + i);
+            const bool in = (xr < (unsigned)a.W && i < SEG);       // also false for negative columns
+            nbp[q] = in ? rp[xr] : 0u;
+            nsr[q] = (stats && in) ? sp[xr] : 0.f;
+            nir[q] = stats ? (in ? ip[xr] : __builtin_nanf("")) : 0.f;
         }
     };
-    auto publish = [&](bool stats) {
+    auto publish = [&](bool stats, bool warm) {
 #pragma unroll
         for (int q = 0; q < NSTG; q++) {
             const int i = lane + 64 * q;
             if (i < SEG) {
+                const uint32_t bp = warm ? (nbp[q] & 0x0000FFFFu) : nbp[q];   // warm-up rows: nothing leaves the window yet
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const int pos = i + ((4 - c) & 3);
-                    sArr[(0 * 4 + c) * LENP + pos] = __builtin_bit_cast(float, nbp[q]);
+                    sArr[(0 * 4 + c) * LENP + pos] = __builtin_bit_cast(float, bp);
                     if (stats) {
                         sArr[(1 * 4 + c) * LENP + pos] = nsr[q];
                         sArr[(2 * 4 + c) * LENP + pos] = nir[q];
@@ -588,15 +592,15 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
             }
         }
     };
-    fetch(yb0 - R, yb0 - 2 * R, false, true);
-    publish(false);
+    fetch(yb0 - R, yb0 - 2 * R, false);
+    publish(false, true);
 
     for (int t = 0; t < T; t++) {
         const int ynew = yb0 - R + t;
         const bool score = (t >= 2 * R);
         const int yout = ynew - R;
         const bool have_next = (t + 1 < T);
-        if (have_next) fetch(ynew + 1, yout + 1, t + 1 >= 2 * R, t + 1 < WN);
+        if (have_next) fetch(ynew + 1, yout + 1, t + 1 >= 2 * R);
 
         // ---- column sums: add the entering row, drop the leaving row (one v_dot2c each) ----
         // groups of 16 columns, loads one group ahead of the arithmetic
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
 
         // the LDS image is single-buffered: every read of this row was issued above, LDS executes a
         // wavefront's operations in order, so the next row may be written now
-        if (have_next) publish(t + 1 >= 2 * R);
+        if (have_next) publish(t + 1 >= 2 * R, t + 1 < WN);
     }
 }
 
@@ -986,7 +990,7 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
         return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: the second-peak output supports at most 1024 disparities");
     a.nchunk = total_chunks;
 #define NCC_WT(RR) 32
-#define NCC_MW(RR) ((RR) <= 11 ? 5 : 3)
+#define NCC_MW(RR) ((RR) <= 11 ? 5 : 4)
 #define NCC_CASE(RR) case RR: rc = d_peak2 ? ncc_launch<RR, 32>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
                                : ncc_launch_fast<RR, NCC_WT(RR), NCC_MW(RR)>(ctx, a, d_disp, d_peak, d_idisp); break;
     switch (r) {
