@@ -151,36 +151,53 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
 #pragma unroll
     for (int k = 0; k < NC; k++) C[k] = 0;
 
-    auto stage = [&](int ynew, int yout, bool stats, bool warm) {
+    // The next row is fetched into registers while the current row is processed and written to LDS
+    // at the end of the iteration (a wavefront's LDS operations execute in order), so the global
+    // memory latency is hidden behind a whole row of arithmetic.
+    constexpr int NSTG = (SEG + 63) / 64;
+    int nvn[NSTG], nvo[NSTG], nvs[NSTG]; float nvi[NSTG];
+    auto fetch = [&](int ynew, int yout, bool stats, bool warm) {
+        const int yold = ynew - WN;
+        const int32_t* rn = gR + (size_t)ynew * P;
+        const int32_t* ro = gR + (size_t)(yold >= 0 ? yold : 0) * P;
+        const int32_t* rs = gSR + (size_t)(stats ? yout : 0) * P;
+        const float* ri = gIR + (size_t)(stats ? yout : 0) * P;
+        const bool old_ok = !warm && yold >= 0;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
+        for (int q = 0; q < NSTG; q++) {
+            const int i = lane + 64 * q;
+            const unsigned xr = (unsigned)(xr0 + i);
+            const bool in = (xr < (unsigned)a.W && i < SEG);
+            nvn[q] = in ? rn[xr] : 0;
+            nvo[q] = (in && old_ok) ? ro[xr] : 0;
+            nvs[q] = (stats && in) ? rs[xr] : 0;
+            nvi[q] = stats ? (in ? ri[xr] : __builtin_nanf("")) : 0.f;
+        }
+    };
+    auto publish = [&]() {
+#pragma unroll
+        for (int q = 0; q < NSTG; q++) {
             const int i = lane + 64 * q;
             if (i >= SEG) continue;
-            const int xr = xr0 + i;
-            const bool in = (xr >= 0 && xr < a.W);
-            const int yold = ynew - WN;
-            const int vn = in ? gR[(size_t)ynew * P + xr] : 0;
-            const int vo = (in && !warm && yold >= 0) ? gR[(size_t)yold * P + xr] : 0;
-            const int vs = (stats && in) ? gSR[(size_t)yout * P + xr] : 0;
-            const float vi = stats ? (in ? gIR[(size_t)yout * P + xr] : __builtin_nanf("")) : 0.f;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int pos = i + ((4 - c) & 3);
-                sArr[(0 * 4 + c) * LENP + pos] = vn;
-                sArr[(1 * 4 + c) * LENP + pos] = vo;
-                sArr[(2 * 4 + c) * LENP + pos] = vs;
-                sArr[(3 * 4 + c) * LENP + pos] = __builtin_bit_cast(int, vi);
+                sArr[(0 * 4 + c) * LENP + pos] = nvn[q];
+                sArr[(1 * 4 + c) * LENP + pos] = nvo[q];
+                sArr[(2 * 4 + c) * LENP + pos] = nvs[q];
+                sArr[(3 * 4 + c) * LENP + pos] = __builtin_bit_cast(int, nvi[q]);
             }
         }
     };
+    fetch(yb0 - R, yb0 - 2 * R, false, true);
+    publish();
 
     for (int t = 0; t < T; t++) {
         const int ynew = yb0 - R + t;
-        const bool warm = (t < WN);
         const bool score = (t >= 2 * R);
         const int yout = ynew - R;
-        stage(ynew, yout, score, warm);
-        // a wavefront's LDS operations execute in order: the reads below see the row just written
+        const bool have_next = (t + 1 < T);
+        if (have_next) fetch(ynew + 1, yout + 1, t + 1 >= 2 * R, t + 1 < WN);
 
         const int4* bn4 = (const int4*)(sArr + (0 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
         const int4* bo4 = (const int4*)(sArr + (1 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
@@ -235,6 +252,7 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
             if (mycol < WT && x < a.W - R)
                 oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red;
         }
+        if (have_next) publish();
     }
 }
 
