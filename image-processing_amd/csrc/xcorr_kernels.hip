@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsig
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* g = (float*)smem_raw;                    // 151 taps (152 slots)
-    float* nrow = g + 152;                          // w normalised samples
-    float* prow = nrow + w;                         // w + 150 reflected samples
+    float* prow = g + 152;                          // w + 150 reflected samples, 16-byte aligned, zero padded to w + 160
+    float* nrow = prow + ((w + 163) & ~3);          // w normalised samples
     const int t = blockIdx.y, y = blockIdx.x;
     const float mn = __uint_as_float(minmax[2 * t]), mx = __uint_as_float(minmax[2 * t + 1]);
     const float range = mx - mn;
@@ -299,18 +299,54 @@ __global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsig
     }
     __syncthreads();
     const int kw = (w == 1) ? 1 : XC_GAUSS_K, rx = kw / 2;
-    for (int i = threadIdx.x; i < w + kw - 1; i += blockDim.x) {
-        const int sx = reflect101(i - rx, w);
-        prow[i] = (sx < w2 && y < h2) ? nrow[sx] : 0.f;
+    for (int i = threadIdx.x; i < ((w + 163) & ~3); i += blockDim.x) {
+        float v = 0.f;
+        if (i < w + kw - 1) {
+            const int sx = reflect101(i - rx, w);
+            v = (sx < w2 && y < h2) ? nrow[sx] : 0.f;
+        }
+        prow[i] = v;
     }
     __syncthreads();
     float* trow = tmp + ((size_t)t * h + y) * w;
-    for (int x = threadIdx.x; x < w; x += blockDim.x) {
-        float acc = 0.f;
-        if (kw == 1) acc = prow[x];
-        else
-            for (int k = 0; k < XC_GAUSS_K; k++) acc = __fadd_rn(acc, __fmul_rn(prow[x + k], g[k]));
-        trow[x] = acc;
+    if (kw == 1) {
+        for (int x = threadIdx.x; x < w; x += blockDim.x) trow[x] = prow[x];
+        return;
+    }
+    // four adjacent outputs per thread: the taps slide through registers, so every padded sample and
+    // every coefficient is read from LDS once per four outputs (16-byte reads); each output still
+    // accumulates its taps left to right with separate multiply and add
+    for (int x0 = 4 * threadIdx.x; x0 < w; x0 += 4 * blockDim.x) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float4 v = *(const float4*)(prow + x0);
+#pragma unroll 2
+        for (int k = 0; k + 4 <= XC_GAUSS_K; k += 4) {
+            const float4 n = *(const float4*)(prow + x0 + k + 4);
+            const float4 c = *(const float4*)(g + k);
+            a0 = __fadd_rn(a0, __fmul_rn(v.x, c.x)); a1 = __fadd_rn(a1, __fmul_rn(v.y, c.x));
+            a2 = __fadd_rn(a2, __fmul_rn(v.z, c.x)); a3 = __fadd_rn(a3, __fmul_rn(v.w, c.x));
+            a0 = __fadd_rn(a0, __fmul_rn(v.y, c.y)); a1 = __fadd_rn(a1, __fmul_rn(v.z, c.y));
+            a2 = __fadd_rn(a2, __fmul_rn(v.w, c.y)); a3 = __fadd_rn(a3, __fmul_rn(n.x, c.y));
+            a0 = __fadd_rn(a0, __fmul_rn(v.z, c.z)); a1 = __fadd_rn(a1, __fmul_rn(v.w, c.z));
+            a2 = __fadd_rn(a2, __fmul_rn(n.x, c.z)); a3 = __fadd_rn(a3, __fmul_rn(n.y, c.z));
+            a0 = __fadd_rn(a0, __fmul_rn(v.w, c.w)); a1 = __fadd_rn(a1, __fmul_rn(n.x, c.w));
+            a2 = __fadd_rn(a2, __fmul_rn(n.y, c.w)); a3 = __fadd_rn(a3, __fmul_rn(n.z, c.w));
+            v = n;
+        }
+        {   // taps 148, 149, 150 (151 = 37 * 4 + 3); v holds samples x0+148 .. x0+151
+            const float4 n = *(const float4*)(prow + x0 + 152);
+            const float c0 = g[148], c1 = g[149], c2 = g[150];
+            a0 = __fadd_rn(a0, __fmul_rn(v.x, c0)); a1 = __fadd_rn(a1, __fmul_rn(v.y, c0));
+            a2 = __fadd_rn(a2, __fmul_rn(v.z, c0)); a3 = __fadd_rn(a3, __fmul_rn(v.w, c0));
+            a0 = __fadd_rn(a0, __fmul_rn(v.y, c1)); a1 = __fadd_rn(a1, __fmul_rn(v.z, c1));
+            a2 = __fadd_rn(a2, __fmul_rn(v.w, c1)); a3 = __fadd_rn(a3, __fmul_rn(n.x, c1));
+            a0 = __fadd_rn(a0, __fmul_rn(v.z, c2)); a1 = __fadd_rn(a1, __fmul_rn(v.w, c2));
+            a2 = __fadd_rn(a2, __fmul_rn(n.x, c2)); a3 = __fadd_rn(a3, __fmul_rn(n.y, c2));
+        }
+        if (x0 < w) trow[x0] = a0;
+        if (x0 + 1 < w) trow[x0 + 1] = a1;
+        if (x0 + 2 < w) trow[x0 + 2] = a2;
+        if (x0 + 3 < w) trow[x0 + 3] = a3;
     }
 }
 
@@ -349,21 +385,45 @@ __global__ __launch_bounds__(256) void xc_colblur_argmax(int w, int h, const flo
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int x = x0 + c;
     unsigned long long best = 0;
-    for (int j = rg; j < XC_RB5; j += 4) {
-        const int y = y0 + j;
-        if (x >= w || y >= h) continue;
-        float acc;
-        if (kh == 1) acc = col[(j + ry) * 64 + c];
-        else {
-            acc = __fmul_rn(g[XC_GAUSS_R], col[(j + ry) * 64 + c]);
-            for (int k = 1; k <= XC_GAUSS_R; k++) {
-                const float pair = __fadd_rn(col[(j + ry + k) * 64 + c], col[(j + ry - k) * 64 + c]);
-                acc = __fadd_rn(acc, __fmul_rn(g[XC_GAUSS_R + k], pair));
-            }
+    // eight consecutive rows per thread: the symmetric tap pairs slide through registers (one new
+    // sample on each side per tap for all eight rows); every output still starts from the centre tap
+    // and adds the pairs outward with separate multiply and add
+    constexpr int NR = XC_RB5 / 4;
+    const int j0 = rg * NR;
+    float acc[NR];
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < NR; i++) acc[i] = col[(j0 + i) * 64 + c];
+    } else {
+        float up[NR], dn[NR];            // samples at row + k and row - k
+        const float gc = g[XC_GAUSS_R];
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const float ctr = col[(j0 + i + ry) * 64 + c];
+            acc[i] = __fmul_rn(gc, ctr);
+            up[i] = ctr; dn[i] = ctr;
         }
+#pragma unroll
+        for (int k = 1; k <= XC_GAUSS_R; k++) {      // fully unrolled: the window shifts become register renaming
+            // shift the windows: up[i] <- sample(row_i + k), dn[i] <- sample(row_i - k)
+#pragma unroll
+            for (int i = 0; i < NR - 1; i++) up[i] = up[i + 1];
+            up[NR - 1] = col[(j0 + NR - 1 + ry + k) * 64 + c];
+#pragma unroll
+            for (int i = NR - 1; i > 0; i--) dn[i] = dn[i - 1];
+            dn[0] = col[(j0 + ry - k) * 64 + c];
+            const float gk = g[XC_GAUSS_R + k];
+#pragma unroll
+            for (int i = 0; i < NR; i++) acc[i] = __fadd_rn(acc[i], __fmul_rn(gk, __fadd_rn(up[i], dn[i])));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const int y = y0 + j0 + i;
+        if (x >= w || y >= h) continue;
         const size_t o = (size_t)t * h * w + (size_t)y * w + x;
         const float imout = (x < w2 && y < h2) ? surf[o] : 0.f;
-        const float dog = __fsub_rn(imout, acc);
+        const float dog = __fsub_rn(imout, acc[i]);
         if (dog_out) dog_out[o] = dog;
         if (x < w2 && y < h2 && dog > -1.0f) {
             const unsigned long long k = argmax_key(dog, (unsigned)(y * w + x));
@@ -744,7 +804,7 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
     }
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
     {
-        const size_t sh = (size_t)(152 + 2 * w + XC_GAUSS_K) * sizeof(float);
+        const size_t sh = (size_t)(152 + 2 * w + 168) * sizeof(float);
         if (sh > 64 * 1024)
             MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
@@ -800,7 +860,7 @@ static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1
     }
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
     {
-        const size_t sh = (size_t)(152 + 2 * w + XC_GAUSS_K) * sizeof(float);
+        const size_t sh = (size_t)(152 + 2 * w + 168) * sizeof(float);
         if (sh > 64 * 1024)
             MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
