@@ -484,7 +484,7 @@ struct NccWaveCfg {
     static constexpr int NC = WT + 2 * R;
     static constexpr int NCP = (NC + 3) & ~3;
     static constexpr int SEG = NCP + 64 + 4;                       // staged right-image columns
-    static constexpr int LENP = ((SEG + 3 + 47) / 64) * 64 + 16;   // >= SEG + 3, == 16 (mod 64)
+    static constexpr int LENP = ((SEG + 7 + 47) / 64) * 64 + 16;   // >= SEG + 7, == 16 (mod 64)
 };
 
 template <int R, int WT, int MW>
@@ -500,6 +500,11 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
     constexpr int NCP = Cfg::NCP, SEG = Cfg::SEG, LENP = Cfg::LENP;
     constexpr int GA = MW >= 5 ? 8 : 16, GB = MW >= 5 ? 4 : 8;      // columns per software-pipeline stage
     __shared__ __attribute__((aligned(16))) float sArr[12 * LENP];   // [3 arrays][4 copies][LENP]
+    // Copy c of an array holds element i at i + ((4 - c) & 3): a lane whose run starts at element e
+    // reads copy e & 3 from a 16-byte aligned position.  The 16 lanes that one ds_read_b128 cycle
+    // serves use all four copies; copies 1..3 read 4 words further in than copy 0, so they start
+    // 4 words early (LENP % 64 == 16 then puts the four copies on disjoint bank quarters).
+#define NCC_COPY(arr, c) (((arr) * 4 + (c)) * LENP - ((c) ? 4 : 0))
 
     const int lane = threadIdx.x;
     // Workgroups are dealt to the 8 XCDs round-robin (ids b and b+8 share an L2).  Remap the id so
@@ -583,10 +588,10 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const int pos = i + ((4 - c) & 3);
-                    sArr[(0 * 4 + c) * LENP + pos] = __builtin_bit_cast(float, bp);
+                    sArr[NCC_COPY(0, c) + pos] = __builtin_bit_cast(float, bp);
                     if (stats) {
-                        sArr[(1 * 4 + c) * LENP + pos] = nsr[q];
-                        sArr[(2 * 4 + c) * LENP + pos] = nir[q];
+                        sArr[NCC_COPY(1, c) + pos] = nsr[q];
+                        sArr[NCC_COPY(2, c) + pos] = nir[q];
                     }
                 }
             }
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
         // ---- column sums: add the entering row, drop the leaving row (one v_dot2c each) ----
         // groups of 16 columns, loads one group ahead of the arithmetic
         {
-            const float4* bp4 = (const float4*)(sArr + (0 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
+            const float4* bp4 = (const float4*)(sArr + NCC_COPY(0, cA) + loff + ((4 - cA) & 3));
             const uint32_t* lrow = gLpack + (size_t)ynew * P + (x0 - R);
             constexpr int NGA = (NCP + GA - 1) / GA;
             float bv[2][GA];
@@ -644,8 +649,8 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
         }
 
         if (score) {
-            const float4* sr4 = (const float4*)(sArr + (1 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
-            const float4* ir4 = (const float4*)(sArr + (2 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
+            const float4* sr4 = (const float4*)(sArr + NCC_COPY(1, cB) + offB + ((4 - cB) & 3));
+            const float4* ir4 = (const float4*)(sArr + NCC_COPY(2, cB) + offB + ((4 - cB) & 3));
             const float* ncrow = gNegc + (size_t)yout * P + (x0 - R);
             const float* ngrow = gNegg + (size_t)yout * P + (x0 - R);
             float S = 0.f;
