@@ -221,6 +221,7 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
             if ((kb & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // keeps the scalar loads of later columns from piling up
         }
 
+        float red = 0.f;
         if (score) {
             const int4* sr4 = (const int4*)(sArr + (2 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
             const float4* ir4 = (const float4*)(sArr + (3 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
@@ -247,12 +248,16 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
                 }
                 if ((g & 3) == 3) q[g >> 2] = tr.q;
             }
-            const float red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
+            red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
+        }
+        if (have_next) publish();
+        // the store comes after publish: vector memory operations complete in order, and publish
+        // waits for the prefetched row
+        if (score) {
             const int x = x0 + mycol;
             if (mycol < WT && x < a.W - R)
                 oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red;
         }
-        if (have_next) publish();
     }
 }
 

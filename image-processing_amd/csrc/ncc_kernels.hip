@@ -648,6 +648,7 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
             }
         }
 
+        float red = 0.f;
         if (score) {
             const float4* sr4 = (const float4*)(sArr + NCC_COPY(1, cB) + offB + ((4 - cB) & 3));
             const float4* ir4 = (const float4*)(sArr + NCC_COPY(2, cB) + offB + ((4 - cB) & 3));
@@ -703,15 +704,119 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
                 ncc_pin(S);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const float red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
-            const int x = x0 + mycol;
-            if (mycol < WT && x < a.W - R)
-                oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red;
+            red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
         }
 
         // the LDS image is single-buffered: every read of this row was issued above, LDS executes a
         // wavefront's operations in order, so the next row may be written now
         if (have_next) publish(t + 1 >= 2 * R, t + 1 < WN);
+        // The key store comes after publish: vector memory operations complete in order, so waiting
+        // for the prefetched row (inside publish) would otherwise also wait for this store's
+        // acknowledgement, a full memory round trip per row.
+        if (score) {
+            const int x = x0 + mycol;
+            if (mycol < WT && x < a.W - R)
+                oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red;
+        }
+    }
+}
+
+// Tail kernel: the few disparities left over when the search range is not a multiple of 64
+// (+-256 is 513 disparities: eight full chunks and one disparity).  A whole chunk wavefront for them
+// would idle 63 of its 64 lanes, so they are scored the other way round: lane <-> column, a loop
+// over the nt <= NCC_TAIL_MAX disparities.  Column sums slide down a band of rows in registers
+// (the same v_dot2c on the packed row pairs), the horizontal window sum goes through LDS.  Output:
+// one more key plane in the format of the argmax kernel (plane `chunk`, tags relative to it).
+#define NCC_TAIL_MAX 4
+#define NCC_TAIL_TW 256
+#define NCC_TAIL_RB 4        // rows whose operands are fetched together (one memory round trip per batch)
+template <int R>
+__global__ __launch_bounds__(320) void ncc_tail_kernel(
+    NccArgs a, int d0, int nt, int chunk,
+    const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
+    const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr, const float* __restrict__ gRir,
+    float* __restrict__ oKeys)
+{
+    constexpr int WN = 2 * R + 1, TW = NCC_TAIL_TW, NCOL = TW + 2 * R, RB = NCC_TAIL_RB;
+    __shared__ float sC[RB][NCC_TAIL_MAX][NCOL + 2];
+    const int tid = threadIdx.x;
+    const int x0 = R + blockIdx.x * TW;               // first output column of the workgroup
+    const int xc = x0 - R + tid;                      // column whose sums this thread carries
+    const bool carry = tid < NCOL && xc < a.W;
+    const int yb0 = a.row0 + blockIdx.y * a.band_rows;
+    const int yb1 = min(yb0 + a.band_rows, a.row1);
+    if (yb0 >= yb1) return;
+    const int T = 2 * R + (yb1 - yb0);
+    const int P = a.pitch;
+    const int x = x0 + tid;
+    const bool outcol = tid < TW && x < a.W - R;
+    float C[NCC_TAIL_MAX];
+#pragma unroll
+    for (int j = 0; j < NCC_TAIL_MAX; j++) C[j] = 0.f;
+
+    // The walk down the band is latency bound (little arithmetic per row), so the operands of RB
+    // rows are requested together and the rows are then processed back to back.
+    for (int t0 = 0; t0 < T; t0 += RB) {
+        uint32_t lp[RB], rp[RB][NCC_TAIL_MAX];
+        float nc[RB], ng[RB], srv[RB][NCC_TAIL_MAX], irv[RB][NCC_TAIL_MAX];
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            const int t = t0 + b;
+            const int ynew = min(yb0 - R + t, a.H - 1);            // rows past the band are fetched but not used
+            const bool live = t < T;
+            lp[b] = (live && carry) ? gLpack[(size_t)ynew * P + xc] : 0u;
+#pragma unroll
+            for (int j = 0; j < NCC_TAIL_MAX; j++) {
+                const unsigned u = (unsigned)(xc - (d0 + j));
+                rp[b][j] = (live && j < nt && carry && u < (unsigned)a.W) ? gRpack[(size_t)ynew * P + u] : 0u;
+            }
+            nc[b] = ng[b] = 0.f;
+            const bool sc_row = live && t >= 2 * R && outcol;
+            const int yout = ynew - R;
+            if (sc_row) { nc[b] = gNegc[(size_t)yout * P + (x - R)]; ng[b] = gNegg[(size_t)yout * P + (x - R)]; }
+#pragma unroll
+            for (int j = 0; j < NCC_TAIL_MAX; j++) {
+                const int d = d0 + j, u = x - d;
+                const bool ok = (sc_row && j < nt && d <= a.dmax && u >= R && u < a.W - R);
+                srv[b][j] = ok ? gRsr[(size_t)yout * P + u] : 0.f;
+                irv[b][j] = ok ? gRir[(size_t)yout * P + u] : __builtin_nanf("");
+            }
+        }
+        // column sums of the RB rows, published to LDS
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            const int t = t0 + b;
+            const uint32_t keep = (t < WN) ? 0x0000FFFFu : 0xFFFFFFFFu;   // warm-up rows: nothing leaves the window yet
+#pragma unroll
+            for (int j = 0; j < NCC_TAIL_MAX; j++)
+                if (j < nt) {
+                    C[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, lp[b]), __builtin_bit_cast(half2_t, rp[b][j] & keep), C[j], false);
+                    if (tid < NCOL) sC[b][j][tid] = C[j];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            const int t = t0 + b;
+            if (t < 2 * R || t >= T || !outcol) continue;
+            const int yout = yb0 - R + t - R;
+            float best = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < NCC_TAIL_MAX; j++) {
+                if (j < nt) {
+                    float S = 0.f;
+#pragma unroll
+                    for (int i = 0; i < WN; i++) S += sC[b][j][tid + i];       // exact: integers below 2^24
+                    const float tt = __builtin_fmaf(nc[b], srv[b][j], S);
+                    const float cov = __builtin_fmaf(ng[b], srv[b][j], tt);
+                    const float sc = __builtin_fmaf(cov, irv[b][j], 0.f);      // NaN where this disparity is not valid
+                    const float key = ncc_make_key(sc, 63u - (uint32_t)(d0 + j - (a.dmin + chunk * 64)));
+                    if (key > best) best = key;                                // NaN never wins
+                }
+            }
+            oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = best;
+        }
+        __syncthreads();
     }
 }
 
@@ -916,21 +1021,31 @@ template <int R, int WT, int MW>
 static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
 {
     NccWs* w = ctx->ncc;
-    const size_t keys_bytes = (size_t)a.nchunk * a.H * a.W * sizeof(float);
+    // a short remainder of the range (nd % 64 disparities) goes to the tail kernel instead of a
+    // chunk wavefront that would idle most of its lanes
+    const int nd = a.dmax - a.dmin + 1;
+    const int rem = nd % 64, nfull = nd / 64;
+    const bool tail = (rem > 0 && rem <= NCC_TAIL_MAX && nfull >= 1);
+    const int nplanes = a.nchunk;                    // key planes the refinement merges
+    const size_t keys_bytes = (size_t)nplanes * a.H * a.W * sizeof(float);
     int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, keys_bytes);
     if (rc) return rc;
     a.nstrips = (a.W - 2 * R + WT - 1) / WT;
     a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
+    if (tail) a.nchunk = nfull;
     hipLaunchKernelGGL((ncc_argmax_kernel<R, WT, MW>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
                        a, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+    if (tail)
+        hipLaunchKernelGGL(ncc_tail_kernel<R>, dim3((a.W - 2 * R + NCC_TAIL_TW - 1) / NCC_TAIL_TW, a.nbands), dim3(320), 0, ctx->stream,
+                           a, a.dmin + nfull * 64, rem, nfull, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
     mis_prof_mark(ctx);
     {
-        const size_t lds = NccRefineCfg<R>::lds_bytes(a.dmax - a.dmin + 1);
+        const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
         if (lds > 64 * 1024)
             MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(ncc_refine_kernel<R>, dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
                            lds, ctx->stream,
-                           a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, a.nchunk, d_disp, d_peak, d_idisp);
+                           a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nplanes, d_disp, d_peak, d_idisp);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
