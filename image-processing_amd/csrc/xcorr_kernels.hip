@@ -102,47 +102,104 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// Up to three consecutive radix-2 stages are done in registers by the thread that owns the 2^S
+// elements they connect (indices base + m * 2^l_lo, m = 0 .. 2^S - 1): the arithmetic is exactly
+// that of S radix-2 passes, with a third of the LDS traffic and barriers.
+// Stage with half = 2^l: butterfly (i, i + half), twiddle index (i mod half) << (logn - 1 - l).
+template <int S>
+__device__ __forceinline__ void fft_dif_pass(float2* x, int logn, int cnt, int l_hi, const float2* __restrict__ tw)
+{
+    constexpr int M = 1 << S;
+    const int l_lo = l_hi - S + 1;
+    const int n = 1 << logn;
+    const int gps = n >> S;                        // groups per sequence
+    const int groups = cnt * gps;
+    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+        const int seq = g / gps, gi = g - seq * gps;
+        const int low = gi & ((1 << l_lo) - 1), high = gi >> l_lo;
+        const int i0 = (high << (l_hi + 1)) + low;            // index of element m = 0 inside the sequence
+        float2* px = x + (size_t)seq * n + i0;
+        float2 v[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) v[m] = px[m << l_lo];
+#pragma unroll
+        for (int st = 0; st < S; st++) {
+            const int l = l_hi - st;
+            const int hm = M >> (st + 1);                      // partner distance in units of m
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                if (m & hm) continue;
+                const int k = (i0 + (m << l_lo)) & ((1 << l) - 1);
+                const float2 w = tw[k << (logn - 1 - l)];
+                const float2 a = v[m], c = v[m + hm];
+                v[m] = make_float2(a.x + c.x, a.y + c.y);
+                v[m + hm] = cmul(make_float2(a.x - c.x, a.y - c.y), w);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++) px[m << l_lo] = v[m];
+    }
+    __syncthreads();
+}
+
 // forward (sign -1), decimation in frequency: natural order in, bit-reversed order out
 __device__ void fft_dif_fwd(float2* x, int logn, int cnt, const float2* __restrict__ tw)
 {
-    const int n = 1 << logn;
-    const int total = cnt << (logn - 1);          // butterflies per pass
-    for (int lh = logn - 1; lh >= 0; lh--) {      // half = 2^lh
-        const int half = 1 << lh;
-        for (int b = threadIdx.x; b < total; b += blockDim.x) {
-            const int s = b >> (logn - 1);
-            const int j = b & ((n >> 1) - 1);
-            const int k = j & (half - 1);
-            const int i0 = s * n + ((j >> lh) << (lh + 1)) + k;
-            const float2 a = x[i0], c = x[i0 + half];
-            const float2 w = tw[k << (logn - 1 - lh)];
-            x[i0] = make_float2(a.x + c.x, a.y + c.y);
-            x[i0 + half] = cmul(make_float2(a.x - c.x, a.y - c.y), w);
-        }
-        __syncthreads();
+    int l = logn - 1;
+    while (l >= 0) {
+        if (l >= 2) { fft_dif_pass<3>(x, logn, cnt, l, tw); l -= 3; }
+        else if (l == 1) { fft_dif_pass<2>(x, logn, cnt, l, tw); l -= 2; }
+        else { fft_dif_pass<1>(x, logn, cnt, l, tw); l -= 1; }
     }
+}
+
+template <int S>
+__device__ __forceinline__ void fft_dit_pass(float2* x, int logn, int cnt, int l_lo, const float2* __restrict__ tw)
+{
+    constexpr int M = 1 << S;
+    const int l_hi = l_lo + S - 1;
+    const int n = 1 << logn;
+    const int gps = n >> S;
+    const int groups = cnt * gps;
+    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+        const int seq = g / gps, gi = g - seq * gps;
+        const int low = gi & ((1 << l_lo) - 1), high = gi >> l_lo;
+        const int i0 = (high << (l_hi + 1)) + low;
+        float2* px = x + (size_t)seq * n + i0;
+        float2 v[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) v[m] = px[m << l_lo];
+#pragma unroll
+        for (int st = 0; st < S; st++) {
+            const int l = l_lo + st;
+            const int hm = 1 << st;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                if (m & hm) continue;
+                const int k = (i0 + (m << l_lo)) & ((1 << l) - 1);
+                float2 w = tw[k << (logn - 1 - l)];
+                w.y = -w.y;
+                const float2 a = v[m];
+                const float2 t = cmul(v[m + hm], w);
+                v[m] = make_float2(a.x + t.x, a.y + t.y);
+                v[m + hm] = make_float2(a.x - t.x, a.y - t.y);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++) px[m << l_lo] = v[m];
+    }
+    __syncthreads();
 }
 
 // backward (sign +1), decimation in time: bit-reversed order in, natural order out, unnormalised
 __device__ void fft_dit_inv(float2* x, int logn, int cnt, const float2* __restrict__ tw)
 {
-    const int n = 1 << logn;
-    const int total = cnt << (logn - 1);
-    for (int lh = 0; lh < logn; lh++) {
-        const int half = 1 << lh;
-        for (int b = threadIdx.x; b < total; b += blockDim.x) {
-            const int s = b >> (logn - 1);
-            const int j = b & ((n >> 1) - 1);
-            const int k = j & (half - 1);
-            const int i0 = s * n + ((j >> lh) << (lh + 1)) + k;
-            float2 w = tw[k << (logn - 1 - lh)];
-            w.y = -w.y;
-            const float2 a = x[i0];
-            const float2 t = cmul(x[i0 + half], w);
-            x[i0] = make_float2(a.x + t.x, a.y + t.y);
-            x[i0 + half] = make_float2(a.x - t.x, a.y - t.y);
-        }
-        __syncthreads();
+    int l = 0;
+    while (l < logn) {
+        const int left = logn - l;
+        if (left >= 3) { fft_dit_pass<3>(x, logn, cnt, l, tw); l += 3; }
+        else if (left == 2) { fft_dit_pass<2>(x, logn, cnt, l, tw); l += 2; }
+        else { fft_dit_pass<1>(x, logn, cnt, l, tw); l += 1; }
     }
 }
 
