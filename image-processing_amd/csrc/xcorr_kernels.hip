@@ -238,8 +238,10 @@ __global__ __launch_bounds__(256) void xc_rows_fwd(XcImage im, const mis_rect* _
         }
         x[i] = make_float2(v, 0.f);
     }
+    float2* stw = x + (size_t)RB * w;               // twiddles in LDS: every butterfly reads one
+    for (int i = threadIdx.x; i < w / 2; i += blockDim.x) stw[i] = tw[i];
     __syncthreads();
-    fft_dif_fwd(x, logw, RB, tw);
+    fft_dif_fwd(x, logw, RB, stw);
     float2* out = spec + ((size_t)(t * 2 + side) * h + row0) * w;
     for (int i = threadIdx.x; i < RB * w; i += blockDim.x) out[i] = x[i];
 }
@@ -260,8 +262,10 @@ __global__ __launch_bounds__(512) void xc_cols(int w, int h, int logh, int CB, f
         A[c * h + r] = sa[(size_t)r * w + c0 + c];
         B[c * h + r] = sb[(size_t)r * w + c0 + c];
     }
+    float2* stw = B + (size_t)CB * h;
+    for (int i = threadIdx.x; i < h / 2; i += blockDim.x) stw[i] = tw[i];
     __syncthreads();
-    fft_dif_fwd(A, logh, 2 * CB, tw);        // A and B are adjacent: 2*CB sequences
+    fft_dif_fwd(A, logh, 2 * CB, stw);       // A and B are adjacent: 2*CB sequences
     // runFFT divides each spectrum by sqrt(N) (image3.cpp:331-334); product image3.cpp:392-394
     for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
         float2 a = A[i], b = B[i];
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(512) void xc_cols(int w, int h, int logh, int CB, f
         A[i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
     }
     __syncthreads();
-    fft_dit_inv(A, logh, CB, tw);
+    fft_dit_inv(A, logh, CB, stw);
     for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
         const int r = i / CB, c = i % CB;
         sa[(size_t)r * w + c0 + c] = A[c * h + r];
@@ -300,8 +304,10 @@ __global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, i
     const int t = blockIdx.y, row0 = blockIdx.x * RB;
     const float2* in = spec + ((size_t)(t * 2) * h + row0) * w;
     for (int i = threadIdx.x; i < RB * w; i += blockDim.x) x[i] = in[i];
+    float2* stw = x + (size_t)RB * w;
+    for (int i = threadIdx.x; i < w / 2; i += blockDim.x) stw[i] = tw[i];
     __syncthreads();
-    fft_dit_inv(x, logw, RB, tw);
+    fft_dit_inv(x, logw, RB, stw);
     float* out = surf + ((size_t)t * h + row0) * w;
     float lo = INFINITY, hi = 0.f;
     for (int i = threadIdx.x; i < RB * w; i += blockDim.x) {
@@ -837,7 +843,7 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
         im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
         if (band) hipLaunchKernelGGL(xc_reset_minmax, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax);
         {
-            const size_t sh = (size_t)p.RBw * w * sizeof(float2);
+            const size_t sh = ((size_t)p.RBw * w + w / 2) * sizeof(float2);
             if (sh > 64 * 1024) {
                 MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
                 MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_rows_inv_abs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
@@ -846,13 +852,13 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
                                w, h, p.logw, p.RBw, tww, spec);
         }
         {
-            const size_t sh = (size_t)2 * p.CB * h * sizeof(float2);
+            const size_t sh = ((size_t)2 * p.CB * h + h / 2) * sizeof(float2);
             if (sh > 64 * 1024)
                 MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
             hipLaunchKernelGGL(xc_cols, dim3(w / p.CB, nt), dim3(512), sh, s, w, h, p.logh, p.CB, scale, twh, spec);
         }
         {
-            const size_t sh = (size_t)p.RBw * w * sizeof(float2);
+            const size_t sh = ((size_t)p.RBw * w + w / 2) * sizeof(float2);
             hipLaunchKernelGGL(xc_rows_inv_abs, dim3(h / p.RBw, nt), dim3(256), sh, s, w, h, p.logw, p.RBw, scale,
                                tww, spec, surf, minmax);
         }

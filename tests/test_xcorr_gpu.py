@@ -217,3 +217,12 @@ def test_masked_peak(ctx, rows, cols, nb, pct):
 def test_masked_peak_nothing_above_minus_one(ctx):
     bands = np.full((1, 16, 16), -2.0, np.float32)
     assert ctx.masked_peak(bands, 10) == oracle.masked_peak(bands, 10) == (-1.0, -8, -8)
+
+
+def test_largest_power_of_two_tile_8192(ctx):
+    """The largest tile of the LDS-resident path: one 8192 x 8192 tile (column transform of two
+    8192-point sequences plus twiddles = the whole 160 KB of LDS)."""
+    img1, img2 = _pair(8192, 8192, 321, -123, 10)
+    ctx.upload_pair(img1, img2)
+    peak, ox, oy = ctx.find_offset((0, 0, 8192, 8192), (0, 0, 8192, 8192), 8192, 8192)
+    assert (ox, oy) == (321, -123) and peak == pytest.approx(1.0, abs=1e-4)
