@@ -261,46 +261,90 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
     }
 }
 
-// merge of the chunk keys, exact scores of the winner and its neighbours by direct window sums
+// Merge of the chunk keys, exact scores of the winner and its two neighbours by direct window sums.
+// One workgroup = NCC16_REF_BW consecutive pixels of 4 consecutive rows.  Neighbouring pixels need
+// not agree on their disparity, so instead of per-pixel gathers the workgroup walks the window rows
+// in groups of NCC16_REF_G: each group's left columns and right columns for the WHOLE search range
+// are staged in LDS (int32), every pixel adds the rows of the group that lie in its window.
+#define NCC16_REF_BW 128
+#define NCC16_REF_G 8
 template <int R>
-__global__ __launch_bounds__(256) void ncc16_refine_kernel(
+struct Ncc16RefineCfg {
+    static constexpr int LC = NCC16_REF_BW + 2 * R;
+    static int right_cols(int nd) { return NCC16_REF_BW + (nd - 1) + 2 * R + 3; }
+    static size_t lds_bytes(int nd) { return (size_t)NCC16_REF_G * (LC + right_cols(nd)) * sizeof(int32_t); }
+};
+
+template <int R>
+__global__ __launch_bounds__(512) void ncc16_refine_kernel(
     NccArgs a, const int32_t* __restrict__ gL, const int32_t* __restrict__ gR,
     const int32_t* __restrict__ gSL, const float* __restrict__ gIL, const int32_t* __restrict__ gSR,
     const float* __restrict__ gIR, const float* __restrict__ gKeys, int nchunk,
     float* __restrict__ oDisp, float* __restrict__ oPeak, int16_t* __restrict__ oIdisp)
 {
-    const int x = R + blockIdx.x * 256 + threadIdx.x;
-    const int y = a.row0 + blockIdx.y;
-    if (x >= a.W - R) return;
+    constexpr int LC = Ncc16RefineCfg<R>::LC, G = NCC16_REF_G;
+    extern __shared__ int32_t ncc16_refine_lds[];
+    const int NC = NCC16_REF_BW + (a.dmax - a.dmin) + 2 * R + 3;
+    int32_t* tL = ncc16_refine_lds;               // [G][LC]
+    int32_t* tR = ncc16_refine_lds + G * LC;      // [G][NC]
+    const int tid = threadIdx.x;
+    const int lx = tid & (NCC16_REF_BW - 1), ly = tid / NCC16_REF_BW;
+    const int x0 = R + blockIdx.x * NCC16_REF_BW;
+    const int y0 = a.row0 + 4 * blockIdx.y;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool inside = (x < a.W - R) && (y < a.row1);
     const int P = a.pitch;
     const size_t o = (size_t)y * a.out_pitch + x;
     int ds = MIS_INVALID_DISP;
-    {
+    if (inside) {
         float best = -1.0e30f;
         for (int c = 0; c < nchunk; c++) {
             const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * a.H * a.out_pitch + o]);
             const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
             if (v > best) { best = v; ds = a.dmin + c * 64 + 63 - (int)(kb & 63u); }
         }
+        if (oIdisp) oIdisp[o] = (int16_t)ds;
+        if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; }
     }
-    if (oIdisp) oIdisp[o] = (int16_t)ds;
-    if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; return; }
-    const int u = x - ds;
-    double Sm = 0.0, S0 = 0.0, Sp = 0.0;         // disparities ds-1, ds, ds+1 <-> right columns u+1, u, u-1
-    for (int j = -R; j <= R; j++) {
-        const int32_t* lr = gL + (size_t)(y + j) * P;
-        const int32_t* rr = gR + (size_t)(y + j) * P;
-        double rb = (double)rr[min(max(u - R, 0), P - 1)], rc = (double)rr[min(max(u - R - 1, 0), P - 1)];
-#pragma unroll 4
-        for (int i = -R; i <= R; i++) {
-            const double l = (double)lr[x + i];
-            const double ra = (double)rr[min(max(u + i + 1, 0), P - 1)];
-            Sm = __builtin_fma(l, ra, Sm);
-            S0 = __builtin_fma(l, rb, S0);
-            Sp = __builtin_fma(l, rc, Sp);
-            rc = rb; rb = ra;
+    const bool valid = inside && ds != MIS_INVALID_DISP;
+    const int u = valid ? x - ds : x0 - a.dmax;   // window centre in the right image (any in-range value when idle)
+    const int cbase = x0 - a.dmax - R - 1;        // raster column of right-tile column 0
+    double Sm = 0.0, S0 = 0.0, Sp = 0.0;          // disparities ds-1, ds, ds+1 <-> right columns u+1, u, u-1
+    const int32_t* pl = tL + lx;                              // column x-R
+    const int32_t* pr = tR + (u - R - 1 - cbase);             // column u-R-1
+
+    const int ylo = y0 - R, yhi = min(y0 + 3, a.row1 - 1) + R;   // window rows of the 4 output rows
+    for (int yg = ylo; yg <= yhi; yg += G) {
+        __syncthreads();                           // the previous group has been consumed
+        for (int j = 0; j < G; j++) {
+            const int row = min(yg + j, a.H - 1);
+            const int32_t* lrow = gL + (size_t)row * P + (x0 - R);
+            const int32_t* rrow = gR + (size_t)row * P;
+            for (int c = tid; c < LC; c += 512) tL[j * LC + c] = lrow[c];
+            for (int c = tid; c < NC; c += 512) tR[j * NC + c] = rrow[min(max(cbase + c, 0), P - 1)];
+        }
+        __syncthreads();
+        if (!valid) continue;
+#pragma unroll 1
+        for (int j = 0; j < G; j++) {
+            const int row = yg + j;
+            if (row < y - R || row > y + R) continue;          // wave-uniform: a wavefront is one row
+            const int32_t* plj = pl + j * LC;
+            const int32_t* prj = pr + j * NC;
+            double rc = (double)prj[0], rb = (double)prj[1];
+#pragma unroll
+            for (int i = 0; i <= 2 * R; i++) {
+                const double ra = (double)prj[i + 2];
+                const double l = (double)plj[i];
+                Sm = __builtin_fma(l, ra, Sm);
+                S0 = __builtin_fma(l, rb, S0);
+                Sp = __builtin_fma(l, rc, Sp);
+                rc = rb; rb = ra;
+            }
         }
     }
+    if (!valid) return;
+
     constexpr double NN = (double)((2 * R + 1) * (2 * R + 1));
     const double sl = (double)gSL[(size_t)y * P + (x - R)];
     const float il = gIL[(size_t)y * P + (x - R)];
@@ -366,8 +410,14 @@ static int ncc16_launch(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, i
     hipLaunchKernelGGL((ncc16_argmax_kernel<R, WT>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
                        a, w->Ld, w->R32, w->SLd, w->SR, w->iR, w->keys);
     mis_prof_mark(ctx);
-    hipLaunchKernelGGL(ncc16_refine_kernel<R>, dim3((a.W - 2 * R + 255) / 256, a.row1 - a.row0), dim3(256), 0, ctx->stream,
-                       a, w->L32, w->R32, w->SL, w->iL, w->SR, w->iR, w->keys, a.nchunk, d_disp, d_peak, d_idisp);
+    {
+        const size_t lds = Ncc16RefineCfg<R>::lds_bytes(a.dmax - a.dmin + 1);
+        if (lds > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc16_refine_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ncc16_refine_kernel<R>, dim3((a.W - 2 * R + NCC16_REF_BW - 1) / NCC16_REF_BW, (a.row1 - a.row0 + 3) / 4),
+                           dim3(512), lds, ctx->stream,
+                           a, w->L32, w->R32, w->SL, w->iL, w->SR, w->iR, w->keys, a.nchunk, d_disp, d_peak, d_idisp);
+    }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
