@@ -298,10 +298,17 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
     int ds = MIS_INVALID_DISP;
     if (inside) {
         float best = -1.0e30f;
-        for (int c = 0; c < nchunk; c++) {
-            const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * a.H * a.out_pitch + o]);
-            const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
-            if (v > best) { best = v; ds = a.dmin + c * 64 + 63 - (int)(kb & 63u); }
+        const size_t plane = (size_t)a.H * a.out_pitch;
+        for (int c0 = 0; c0 < nchunk; c0 += 6) {   // six planes per round trip: the loads are independent
+            float k6[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) k6[i] = gKeys[(size_t)min(c0 + i, nchunk - 1) * plane + o];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const uint32_t kb = __builtin_bit_cast(uint32_t, k6[i]);
+                const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
+                if (c0 + i < nchunk && v > best) { best = v; ds = a.dmin + (c0 + i) * 64 + 63 - (int)(kb & 63u); }
+            }
         }
         if (oIdisp) oIdisp[o] = (int16_t)ds;
         if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; }
