@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
             for (int c = 0; c < 4; c++) {
                 const int pos = i + ((4 - c) & 3);
                 sArr[(0 * 4 + c) * LENP + pos] = nvn[q];
-                sArr[(1 * 4 + c) * LENP + pos] = nvo[q];
+                sArr[(1 * 4 + c) * LENP + pos] = -nvo[q];        // the leaving row is staged negated
                 sArr[(2 * 4 + c) * LENP + pos] = nvs[q];
                 sArr[(3 * 4 + c) * LENP + pos] = __builtin_bit_cast(int, nvi[q]);
             }
@@ -212,10 +212,8 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
             for (int e = 0; e < 4; e++) {
                 const int k = 4 * kb + e;
                 if (k < NC) {
-                    const double an = lnew[k];
-                    const double ao = -lold[k];            // its partner bo is staged as 0 while the window fills
-                    C[k] = __builtin_fma(an, (double)bnv[e], C[k]);
-                    C[k] = __builtin_fma(ao, (double)bov[e], C[k]);
+                    C[k] = __builtin_fma(lnew[k], (double)bnv[e], C[k]);
+                    C[k] = __builtin_fma(lold[k], (double)bov[e], C[k]);   // bo: negated leaving row, 0 while the window fills
                 }
             }
             if ((kb & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // keeps the scalar loads of later columns from piling up
