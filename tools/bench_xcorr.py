@@ -42,11 +42,23 @@ def main():
         got = ctx.find_offsets(rects1, rects2, tile, tile)
     dt = (time.perf_counter() - t0) / steps
     n = len(rects1)
+    # CPU side by side: the C oracle's findOffset restatement on a few of the same tiles
+    import oracle
+    ncpu = 6
+    t1 = time.perf_counter()
+    same = 0
+    for k in range(ncpu):
+        o = oracle.find_offset(left, right, rects1[k], rects2[k], tile, tile, precision=0)
+        same += int((o["dx"], o["dy"]) == (int(got["dx"][k]), int(got["dy"][k])))
+    tc = (time.perf_counter() - t1) / ncpu
+    cpu = {"value": round(1.0 / tc, 2), "unit": "tiles/s", "cores": oracle.num_threads(), "kind": "port",
+           "sample": "%d of the same tiles, %.0f ms each; offsets equal to the GPU's on %d" % (ncpu, tc * 1e3, same)}
     print(json.dumps({"metric": "FFT tile correlation", "value": round(n / dt, 1), "unit": "tiles/s",
                       "ms_per_step": round(dt * 1e3, 3), "tiles": n, "tile": tile,
                       "gpx_per_s": round(n * tile * tile / dt / 1e9, 3),
                       "offsets_recovered": hit,
                       "algorithmic_GBps": round(n * (2 * tile * tile + 16) / dt / 1e9, 2),
+                      "cpu_baseline": cpu,
                       "config": {"workload": "BASELINE config[2]: 8192x8192 pair, 256 tiles of 512x512, offsets in [-100,100]^2"}}))
 
 
