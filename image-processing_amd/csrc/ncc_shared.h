@@ -67,14 +67,16 @@ struct NccTree {
     float t0, t1, t2, t3, q;
     __device__ __forceinline__ void push(int jj, float k)
     {
+        // the levels with the most merges use the cheapest steps (two DPP maxima); the lane swaps,
+        // which cost half as much again, are left for the last two levels
         if ((jj & 1) == 0) { t0 = k; return; }
-        const float m1 = ncc_merge32(t0, k);
+        const float m1 = ncc_merge8(t0, k);
         if ((jj & 2) == 0) { t1 = m1; return; }
-        const float m2 = ncc_merge16(t1, m1);
+        const float m2 = ncc_merge4(t1, m1);
         if ((jj & 4) == 0) { t2 = m2; return; }
-        const float m3 = ncc_merge8(t2, m2);
+        const float m3 = ncc_merge32(t2, m2);
         if ((jj & 8) == 0) { t3 = m3; return; }
-        q = ncc_merge4(t3, m3);
+        q = ncc_merge16(t3, m3);
     }
 };
 
