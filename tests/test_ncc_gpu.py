@@ -61,21 +61,27 @@ def test_too_small_frame_is_all_invalid(ctx):
     assert np.all(out["idisp"] == -32768) and np.all(out["peak"] == 0)
 
 
-def test_row_strips_equal_the_full_frame(ctx):
-    """Two row strips computed separately (the multi-GPU partition) equal the full-frame result."""
+@pytest.mark.parametrize("dmin,dmax,dtype", [(-40, 40, np.uint8), (-32, 32, np.uint8), (-70, 59, np.uint16)])
+def test_row_strips_equal_the_full_frame(ctx, dmin, dmax, dtype):
+    """Row strips computed separately (the multi-GPU partition) equal the full-frame result; the
+    second range leaves one disparity to the tail kernel."""
     import torch
     import partition
-    left = synth.texture(90, 300, 21)
+    left = synth.texture(90, 300, 21, dtype)
     right = synth.shift_right_image(left, -12, fill_seed=22)
-    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    if dtype == np.uint16:
+        tl = torch.from_numpy(left.view(np.int16)).cuda().view(torch.uint16)
+        tr = torch.from_numpy(right.view(np.int16)).cuda().view(torch.uint16)
+    else:
+        tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
     ctx.bind_pair_torch(tl, tr)
     full_d = torch.empty((90, 300), dtype=torch.float32, device="cuda")
     full_p = torch.empty_like(full_d)
-    ctx.ncc_dense_torch(11, -40, 40, full_d, full_p)
+    ctx.ncc_dense_torch(11, dmin, dmax, full_d, full_p)
     part_d = torch.full_like(full_d, 12345.0)
     part_p = torch.full_like(full_d, 12345.0)
     for row0, n in partition.row_strips(90, 3):
-        ctx.ncc_dense_torch(11, -40, 40, part_d, part_p, row0=row0, nrows=n)
+        ctx.ncc_dense_torch(11, dmin, dmax, part_d, part_p, row0=row0, nrows=n)
     ctx.synchronize()
     assert torch.equal(full_d, part_d) and torch.equal(full_p, part_p)
 
