@@ -72,3 +72,33 @@ def test_band_of_rows_against_the_oracle(full):
         gpu[k] = gpu[k][r:-r]
     ora = {k: v[r:-r] for k, v in ora.items() if isinstance(v, np.ndarray)}
     compare_ncc(gpu, ora)
+
+
+def test_config2_tiles_recover_their_offsets(ctx):
+    """BASELINE config[2]: 256 tiles of 512 x 512 over an 8192 x 8192 pair, a different integer offset
+    in [-100,100]^2 per tile: every offset recovered, the batched call equal to single-tile calls and
+    to the oracle on a few tiles."""
+    size, tile = 8192, 512
+    seed = 0xC0FFEE + 3
+    left = synth.texture(size, size, seed)
+    nt = size // tile
+    rnd = synth.splitmix64(seed + 1, 2 * nt * nt).reshape(nt * nt, 2)
+    offs = (rnd % np.uint64(201)).astype(np.int64) - 100
+    right = np.empty_like(left)
+    pad = np.pad(left, 128, mode="reflect")
+    rects = []
+    for k in range(nt * nt):
+        j, i = divmod(k, nt)
+        dx, dy = int(offs[k, 0]), int(offs[k, 1])
+        y0, x0 = j * tile + 128 + dy, i * tile + 128 + dx
+        right[j * tile:(j + 1) * tile, i * tile:(i + 1) * tile] = pad[y0:y0 + tile, x0:x0 + tile]
+        rects.append((i * tile, j * tile, tile, tile))
+    ctx.upload_pair(left, right)
+    got = ctx.find_offsets(rects, rects, tile, tile)
+    assert np.array_equal(got["dx"], offs[:, 0]) and np.array_equal(got["dy"], offs[:, 1])
+    for k in (0, 17, 255):
+        peak, dx, dy = ctx.find_offset(rects[k], rects[k], tile, tile)
+        assert (dx, dy) == (got["dx"][k], got["dy"][k]) and np.float32(peak) == got["peak"][k]
+        ref = oracle.find_offset(left, right, rects[k], rects[k], tile, tile, precision=1)
+        assert (dx, dy) == (ref["dx"], ref["dy"])
+        assert abs(peak - ref["peak"]) <= 1e-4 * max(abs(ref["peak"]), 1e-3) + 1e-5
