@@ -61,7 +61,7 @@ void mis_ncc_release(mis_ctx* ctx)
 // its own ring column) and slides the vertical window over them.  |sum p'| < 2^12 and
 // sum p'^2 < 2^19 for windows up to 31, so a ring entry is one 32-bit word.
 // ---------------------------------------------------------------------------------------------
-#define NCC_STATS_BAND 128
+#define NCC_STATS_BAND 64
 template <typename T, bool LEFT>
 __global__ __launch_bounds__(256) void ncc_tables_kernel(const T* __restrict__ img, size_t stride_px,
                                                          int W, int H, int r, int pitch,
@@ -1042,9 +1042,13 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
     if (tail) a.nchunk = nfull;
     // the tail writes its own key plane; it runs first so that the profile marks bracket the argmax kernel alone
-    if (tail)
-        hipLaunchKernelGGL(ncc_tail_kernel<R>, dim3((a.W - 2 * R + NCC_TAIL_TW - 1) / NCC_TAIL_TW, a.nbands), dim3(320), 0, ctx->stream,
-                           a, a.dmin + nfull * 64, rem, nfull, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+    if (tail) {
+        NccArgs ta = a;                              // shorter bands: the tail walk is latency bound and wants more workgroups
+        ta.band_rows = 64;
+        ta.nbands = (a.row1 - a.row0 + ta.band_rows - 1) / ta.band_rows;
+        hipLaunchKernelGGL(ncc_tail_kernel<R>, dim3((a.W - 2 * R + NCC_TAIL_TW - 1) / NCC_TAIL_TW, ta.nbands), dim3(320), 0, ctx->stream,
+                           ta, a.dmin + nfull * 64, rem, nfull, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+    }
     mis_prof_mark(ctx);                            // tables (and tail) done
     hipLaunchKernelGGL((ncc_argmax_kernel<R, WT, MW>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
                        a, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
