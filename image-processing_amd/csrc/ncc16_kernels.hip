@@ -99,7 +99,7 @@ struct Ncc16Cfg {
 // One wavefront per workgroup = (strip of WT columns, band of rows, chunk of 64 disparities).
 // LDS: 4 arrays (entering right row, leaving right row, S_R, 1/sigma_R) x 4 shifted copies.
 template <int R, int WT>
-__global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
+__global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
     NccArgs a, const double* __restrict__ gL, const int32_t* __restrict__ gR,
     const double* __restrict__ gSL, const int32_t* __restrict__ gSR, const float* __restrict__ gIR,
     float* __restrict__ oKeys)
@@ -199,24 +199,43 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
         const bool have_next = (t + 1 < T);
         if (have_next) fetch(ynew + 1, yout + 1, t + 1 >= 2 * R, t + 1 < WN);
 
-        const int4* bn4 = (const int4*)(sArr + (0 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
-        const int4* bo4 = (const int4*)(sArr + (1 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
-        const double* lnew = gL + (size_t)ynew * P + (x0 - R);
-        const int yold = ynew - WN;
-        const double* lold = gL + (size_t)(yold >= 0 ? yold : 0) * P + (x0 - R);
+        // ---- column sums, software pipelined: the operands of 4 columns are requested while the
+        // previous 4 are consumed (explicit wait + scheduling barriers keep that order) ----
+        {
+            const int4* bn4 = (const int4*)(sArr + (0 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
+            const int4* bo4 = (const int4*)(sArr + (1 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
+            const double* lnew = gL + (size_t)ynew * P + (x0 - R);
+            const int yold = ynew - WN;
+            const double* lold = gL + (size_t)(yold >= 0 ? yold : 0) * P + (x0 - R);
+            constexpr int NGA = NCP / 4;
+            int4 bn[2], bo[2];
+            double an[2][4], ao[2][4];
+            auto loadA = [&](int g, int set) {
+                bn[set] = bn4[g]; bo[set] = bo4[g];
 #pragma unroll
-        for (int kb = 0; kb < NCP / 4; kb++) {
-            const int4 bn = bn4[kb], bo = bo4[kb];
-            const int bnv[4] = { bn.x, bn.y, bn.z, bn.w }, bov[4] = { bo.x, bo.y, bo.z, bo.w };
+                for (int e = 0; e < 4; e++)
+                    if (4 * g + e < NC) { an[set][e] = lnew[4 * g + e]; ao[set][e] = lold[4 * g + e]; }
+            };
+            loadA(0, 0);
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int k = 4 * kb + e;
-                if (k < NC) {
-                    C[k] = __builtin_fma(lnew[k], (double)bnv[e], C[k]);
-                    C[k] = __builtin_fma(lold[k], (double)bov[e], C[k]);   // bo: negated leaving row, 0 while the window fills
+            for (int g = 0; g < NGA; g++) {
+                const int set = g & 1;
+                __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): LDS and scalar loads of this group
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < NGA) loadA(g + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int bnv[4] = { bn[set].x, bn[set].y, bn[set].z, bn[set].w };
+                const int bov[4] = { bo[set].x, bo[set].y, bo[set].z, bo[set].w };
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int k = 4 * g + e;
+                    if (k < NC) {
+                        C[k] = __builtin_fma(an[set][e], (double)bnv[e], C[k]);
+                        C[k] = __builtin_fma(ao[set][e], (double)bov[e], C[k]);   // bo: negated leaving row, 0 while the window fills
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if ((kb & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // keeps the scalar loads of later columns from piling up
         }
 
         float red = 0.f;
@@ -229,22 +248,34 @@ __global__ __launch_bounds__(64, 2) void ncc16_argmax_kernel(
             for (int k = 0; k < 2 * R; k++) S += C[k];
             float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
             NccTree tr;
+            constexpr int NGB = WT / 4;
+            int4 s4[2]; float4 i4[2]; double sl[2][4];
+            auto loadB = [&](int g, int set) {
+                s4[set] = sr4[g]; i4[set] = ir4[g];
 #pragma unroll
-            for (int g = 0; g < WT / 4; g++) {
-                const int4 s4 = sr4[g];
-                const float4 i4 = ir4[g];
-                const int srv[4] = { s4.x, s4.y, s4.z, s4.w };
-                const float irv[4] = { i4.x, i4.y, i4.z, i4.w };
+                for (int e = 0; e < 4; e++) sl[set][e] = slrow[4 * g + e];
+            };
+            loadB(0, 0);
+#pragma unroll
+            for (int g = 0; g < NGB; g++) {
+                const int set = g & 1;
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < NGB) loadB(g + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int srv[4] = { s4[set].x, s4[set].y, s4[set].z, s4[set].w };
+                const float irv[4] = { i4[set].x, i4[set].y, i4[set].z, i4[set].w };
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int j = 4 * g + e;
                     S += C[j + 2 * R];
-                    const double num = __builtin_fma(NN, S, -(slrow[j] * (double)srv[e]));   // exact: integers below 2^53
+                    const double num = __builtin_fma(NN, S, -(sl[set][e] * (double)srv[e]));   // exact: integers below 2^53
                     const float sc = __builtin_fmaf((float)num, irv[e], bias);
                     S -= C[j];
                     tr.push(j & 15, ncc_make_key(sc, tag));
                 }
                 if ((g & 3) == 3) q[g >> 2] = tr.q;
+                __builtin_amdgcn_sched_barrier(0);
             }
             red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
         }
