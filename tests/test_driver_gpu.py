@@ -85,3 +85,50 @@ def test_frame_that_is_not_a_power_of_two(ctx):
         assert g[:10] == w[:10]
         assert abs(g[10] - w[10]) <= 1e-4 * max(abs(w[10]), 1e-3) + 1e-5
     assert (got[0][4], got[0][5]) == (9, -5)
+
+
+def _write_pgm(path, img):
+    h, w = img.shape
+    with open(path, "wb") as f:
+        if img.dtype == np.uint8:
+            f.write(b"P5\n# test raster\n%d %d\n255\n" % (w, h)); f.write(img.tobytes())
+        else:
+            f.write(b"P5\n%d %d\n65535\n" % (w, h)); f.write(img.astype(">u2").tobytes())
+
+
+def test_cpp_host_program_on_the_c_abi(ctx, tmp_path):
+    """examples/image3_mi.cpp (plain C++ against include/mi_stereo.h, the reference's main() on the
+    library): its XYZ file, dispersion raster and dense raster equal what the Python binding produces."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(mistereo.LIB_PATH), "image3_mi")
+    assert os.path.exists(exe), "build it with make -C image-processing_amd all"
+    img1, img2 = _shifted_pair(256, 9, -4, 78)
+    left, right = os.path.join(tmp_path, "l.pgm"), os.path.join(tmp_path, "r.pgm")
+    _write_pgm(left, img1); _write_pgm(right, img2)
+    yaml = "%%YAML:1.0\nA: !!opencv-matrix\n   rows: 3\n   cols: 3\n   dt: d\n   data: [ 10000., 0., 128., 0., 10000., 128., 0., 0., 1. ]\n" \
+           "R: !!opencv-matrix\n   rows: 3\n   cols: 3\n   dt: d\n   data: [ 1., 0., 0., 0., 1., 0., 0., 0., 1. ]\n" \
+           "T: !!opencv-matrix\n   rows: 3\n   cols: 1\n   dt: d\n   data: [ %s, 0., -3000. ]\n"
+    open(left + ".yaml", "w").write(yaml % "0.")
+    open(right + ".yaml", "w").write(yaml % "-900.")
+    xyz_path, tif_path, dense_path = (os.path.join(tmp_path, n) for n in ("o.xyz", "d.tif", "n.tif"))
+    r = subprocess.run([exe, left, right, "--xyz", xyz_path, "--dispersion", tif_path, "--min-size", "32",
+                        "--dense", "11", "-20", "20", dense_path], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    # the same through the Python binding
+    ctx.upload_pair(img1, img2)
+    leaves, ntiles = ctx.disparity_map(min_size=32)
+    assert "%d tiles correlated, %d leaves" % (ntiles, len(leaves)) in r.stdout
+    A = [[10000, 0, 128], [0, 10000, 128], [0, 0, 1]]
+    c1 = mistereo.make_camera(A, np.eye(3), [0, 0, -3000])
+    c2 = mistereo.make_camera(A, np.eye(3), [-900, 0, -3000])
+    xyz = ctx.calculate_xyz(c1, c2, np.array([l[6:10] for l in leaves], np.int32))
+    want = ["%f %f %f %f " % (p[0], p[1], p[2], float(img1[l[7], l[6]])) for p, l in zip(xyz, leaves)]
+    assert open(xyz_path).read().splitlines() == want
+    planes = mistereo.rasterize_leaves(leaves, 256, 256, fill=0.0)
+    raw = open(tif_path, "rb").read()
+    assert np.array_equal(np.frombuffer(raw, np.float32, 3 * 256 * 256, 8).reshape(3, 256, 256), planes)
+    dense = ctx.ncc_dense(11, -20, 20, want_idisp=False)
+    raw = open(dense_path, "rb").read()
+    got = np.frombuffer(raw, np.float32, 2 * 256 * 256, 8).reshape(2, 256, 256)
+    assert np.array_equal(got[0].view(np.uint32), dense["disp"].view(np.uint32))
+    assert np.array_equal(got[1].view(np.uint32), dense["peak"].view(np.uint32))
