@@ -214,8 +214,10 @@ def main():
             "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config[1]: %dx%d 8-bit synthetic aerial pair, %dx%d NCC window, +-%d px search (%d disparities) per GPU"
-                                   % (W, H, args.window, args.window, D, nd),
+            "config": {"workload": "%s: %dx%d 8-bit synthetic aerial pair, %dx%d NCC window, +-%d px search (%d disparities) per GPU"
+                                   % ("BASELINE config[1]" if (W, args.window, D) == (8192, 21, 256) else
+                                      "BASELINE config[3] frame size (one of its 16 pairs)" if (W, args.window, D) == (16384, 21, 256) else
+                                      "non-baseline size", W, H, args.window, args.window, D, nd),
                        "window": args.window, "dmin": -D, "dmax": D,
                        "gather_to_rank0": bool(do_gather)},
             "matched_points_per_s": round(matched * world / (dt / max(args.steps, 1) + t_tri), 1),
