@@ -600,39 +600,58 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
     fetch(yb0 - R, yb0 - 2 * R, false);
     publish(false, true);
 
+    // Operand buffers of the two software-pipelined loops (two sets each).  The first group of a
+    // loop is requested before the previous loop's last group is consumed (part B's inside part A,
+    // the next row's part A right after the row image is rewritten), so no wait sees a fresh request.
+    constexpr int NGA = (NCP + GA - 1) / GA, NGB = WT / GB;
+    float bv[2][GA];
+    uint32_t av[2][GA];
+    float sv[2][GB], iv[2][GB], cv[2][GB], gv[2][GB];
+    const float4* bp4 = (const float4*)(sArr + NCC_COPY(0, cA) + loff + ((4 - cA) & 3));
+    const float4* sr4 = (const float4*)(sArr + NCC_COPY(1, cB) + offB + ((4 - cB) & 3));
+    const float4* ir4 = (const float4*)(sArr + NCC_COPY(2, cB) + offB + ((4 - cB) & 3));
+    auto loadA = [&](const uint32_t* lrow, int g, int set) {
+#pragma unroll
+        for (int v = 0; v < GA / 4; v++) {
+            if (GA * g + 4 * v < NCP) {
+                const float4 f = bp4[(GA / 4) * g + v];
+                bv[set][4 * v] = f.x; bv[set][4 * v + 1] = f.y; bv[set][4 * v + 2] = f.z; bv[set][4 * v + 3] = f.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < GA; e++)
+            if (GA * g + e < NCP) av[set][e] = lrow[GA * g + e];
+    };
+    auto loadB = [&](const float* ncrow, const float* ngrow, int g, int set) {
+#pragma unroll
+        for (int v = 0; v < GB / 4; v++) {
+            const float4 f = sr4[(GB / 4) * g + v], h = ir4[(GB / 4) * g + v];
+            sv[set][4 * v] = f.x; sv[set][4 * v + 1] = f.y; sv[set][4 * v + 2] = f.z; sv[set][4 * v + 3] = f.w;
+            iv[set][4 * v] = h.x; iv[set][4 * v + 1] = h.y; iv[set][4 * v + 2] = h.z; iv[set][4 * v + 3] = h.w;
+        }
+#pragma unroll
+        for (int e = 0; e < GB; e++) { cv[set][e] = ncrow[GB * g + e]; gv[set][e] = ngrow[GB * g + e]; }
+    };
+    loadA(gLpack + (size_t)(yb0 - R) * P + (x0 - R), 0, 0);
+
     for (int t = 0; t < T; t++) {
         const int ynew = yb0 - R + t;
         const bool score = (t >= 2 * R);
         const int yout = ynew - R;
         const bool have_next = (t + 1 < T);
         if (have_next) fetch(ynew + 1, yout + 1, t + 1 >= 2 * R);
+        const float* ncrow = gNegc + (size_t)(score ? yout : 0) * P + (x0 - R);
+        const float* ngrow = gNegg + (size_t)(score ? yout : 0) * P + (x0 - R);
 
         // ---- column sums: add the entering row, drop the leaving row (one v_dot2c each) ----
-        // groups of 16 columns, loads one group ahead of the arithmetic
         {
-            const float4* bp4 = (const float4*)(sArr + NCC_COPY(0, cA) + loff + ((4 - cA) & 3));
             const uint32_t* lrow = gLpack + (size_t)ynew * P + (x0 - R);
-            constexpr int NGA = (NCP + GA - 1) / GA;
-            float bv[2][GA];
-            uint32_t av[2][GA];
-            auto loadA = [&](int g, int set) {
-#pragma unroll
-                for (int v = 0; v < GA / 4; v++) {
-                    if (GA * g + 4 * v < NCP) {
-                        const float4 f = bp4[(GA / 4) * g + v];
-                        bv[set][4 * v] = f.x; bv[set][4 * v + 1] = f.y; bv[set][4 * v + 2] = f.z; bv[set][4 * v + 3] = f.w;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < GA; e++)
-                    if (GA * g + e < NCP) av[set][e] = lrow[GA * g + e];
-            };
-            loadA(0, 0);
 #pragma unroll
             for (int g = 0; g < NGA; g++) {
                 const int set = g & 1;
                 NCC_WAIT();
-                if (g + 1 < NGA) loadA(g + 1, set ^ 1);
+                if (g + 1 < NGA) loadA(lrow, g + 1, set ^ 1);
+                else loadB(ncrow, ngrow, 0, 0);          // unconditional: warm-up rows request row 0's tables and drop them
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < GA; e++) {
@@ -650,33 +669,16 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
 
         float red = 0.f;
         if (score) {
-            const float4* sr4 = (const float4*)(sArr + NCC_COPY(1, cB) + offB + ((4 - cB) & 3));
-            const float4* ir4 = (const float4*)(sArr + NCC_COPY(2, cB) + offB + ((4 - cB) & 3));
-            const float* ncrow = gNegc + (size_t)yout * P + (x0 - R);
-            const float* ngrow = gNegg + (size_t)yout * P + (x0 - R);
             float S = 0.f;
 #pragma unroll
             for (int k = 0; k < 2 * R; k++) S += C[k];
             float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
-            constexpr int NGB = WT / GB;
-            float sv[2][GB], iv[2][GB], cv[2][GB], gv[2][GB];
-            auto loadB = [&](int g, int set) {
-#pragma unroll
-                for (int v = 0; v < GB / 4; v++) {
-                    const float4 f = sr4[(GB / 4) * g + v], h = ir4[(GB / 4) * g + v];
-                    sv[set][4 * v] = f.x; sv[set][4 * v + 1] = f.y; sv[set][4 * v + 2] = f.z; sv[set][4 * v + 3] = f.w;
-                    iv[set][4 * v] = h.x; iv[set][4 * v + 1] = h.y; iv[set][4 * v + 2] = h.z; iv[set][4 * v + 3] = h.w;
-                }
-#pragma unroll
-                for (int e = 0; e < GB; e++) { cv[set][e] = ncrow[GB * g + e]; gv[set][e] = ngrow[GB * g + e]; }
-            };
-            loadB(0, 0);
             NccTree tr;
 #pragma unroll
             for (int g = 0; g < NGB; g++) {
                 const int set = g & 1;
                 NCC_WAIT();
-                if (g + 1 < NGB) loadB(g + 1, set ^ 1);
+                if (g + 1 < NGB) loadB(ncrow, ngrow, g + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < GB; e += 2) {
@@ -710,6 +712,9 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
         // the LDS image is single-buffered: every read of this row was issued above, LDS executes a
         // wavefront's operations in order, so the next row may be written now
         if (have_next) publish(t + 1 >= 2 * R, t + 1 < WN);
+        // first group of the next row (unconditional, so that the scalar operands stay in SGPRs; after
+        // the last row it re-reads the current one and is dropped)
+        loadA(gLpack + (size_t)(have_next ? ynew + 1 : ynew) * P + (x0 - R), 0, 0);
         // The key store comes after publish: vector memory operations complete in order, so waiting
         // for the prefetched row (inside publish) would otherwise also wait for this store's
         // acknowledgement, a full memory round trip per row.
