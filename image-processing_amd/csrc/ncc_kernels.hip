@@ -838,8 +838,8 @@ __global__ __launch_bounds__(320) void ncc_tail_kernel(
 template <int R>
 struct NccRefineCfg {
     static constexpr int NQ = (2 * R + 7) / 4 + 1;       // quad rows the windows of 4 consecutive rows can touch
-    static constexpr int LC = NCC_REF_BW + 2 * R;        // left columns of the run
-    static int right_cols(int nd) { return NCC_REF_BW + (nd - 1) + 2 * R + 3; }
+    static constexpr int LC = (NCC_REF_BW + 2 * R + 3) & ~3;     // left columns of the run, row stride a multiple of 4
+    static int right_cols(int nd) { return (NCC_REF_BW + (nd - 1) + 2 * R + 3 + 3) & ~3; }
     static size_t lds_bytes(int nd) { return (size_t)NQ * (LC + right_cols(nd)) * sizeof(uint32_t); }
 };
 
@@ -852,8 +852,8 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
 {
     using Cfg = NccRefineCfg<R>;
     constexpr int NQ = Cfg::NQ, LC = Cfg::LC;
-    extern __shared__ uint32_t ncc_refine_lds[];
-    const int NC = NCC_REF_BW + (a.dmax - a.dmin) + 2 * R + 3;     // == Cfg::right_cols(nd)
+    extern __shared__ __attribute__((aligned(16))) uint32_t ncc_refine_lds[];
+    const int NC = (NCC_REF_BW + (a.dmax - a.dmin) + 2 * R + 3 + 3) & ~3;     // == Cfg::right_cols(nd)
     uint32_t* tL = ncc_refine_lds;               // [NQ][LC]
     uint32_t* tR = ncc_refine_lds + NQ * LC;     // [NQ][NC]
 
@@ -889,12 +889,29 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     const int qb = (y0 - R) >> 2;                 // first staged quad row
     const int nq_rows = (a.H + 3) >> 2;
     const int cbase = x0 - a.dmax - R - 1;        // raster column of right-tile column 0
+    // 16 bytes per thread and load; workgroups whose columns all lie inside the pitch (all but those
+    // at the left and right edge of the raster) skip the per-element clamps
+    const bool interior = (cbase >= 0) && (cbase + NC <= P) && (x0 - R + LC <= P);
     for (int qi = 0; qi < NQ; qi++) {
         const int q = min(qb + qi, nq_rows - 1);
         const uint32_t* lrow = VL + (size_t)q * P + (x0 - R);
         const uint32_t* rrow = VR + (size_t)q * P;
-        for (int c = tid; c < LC; c += 512) tL[qi * LC + c] = lrow[c];
-        for (int c = tid; c < NC; c += 512) tR[qi * NC + c] = rrow[min(max(cbase + c, 0), P - 1)];
+        if (interior) {
+            for (int c4 = tid; c4 < (LC + NC) / 4; c4 += 512) {
+                uint4 v;
+                if (c4 < LC / 4) {
+                    __builtin_memcpy(&v, lrow + 4 * c4, 16);                       // 4-byte aligned
+                    *(uint4*)(tL + qi * LC + 4 * c4) = v;
+                } else {
+                    const int c = 4 * c4 - LC;
+                    __builtin_memcpy(&v, rrow + cbase + c, 16);
+                    *(uint4*)(tR + qi * NC + c) = v;
+                }
+            }
+        } else {
+            for (int c = tid; c < LC; c += 512) tL[qi * LC + c] = lrow[min(c, P - 1 - (x0 - R))];
+            for (int c = tid; c < NC; c += 512) tR[qi * NC + c] = rrow[min(max(cbase + c, 0), P - 1)];
+        }
     }
     __syncthreads();
     if (!valid) return;
@@ -915,14 +932,26 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
         const uint32_t* plq = pl + qi * LC;
         const uint32_t* prq = pr + qi * NC;
         uint32_t rc = prq[0], rb = prq[1];
+        if (m == 0xFFFFFFFFu) {                   // all four rows of the quad lie in the window: no masking
 #pragma unroll
-        for (int i = 0; i <= 2 * R; i++) {
-            const uint32_t ra = prq[i + 2];
-            const uint32_t l = plq[i] & m;
-            Sm = __builtin_amdgcn_sdot4((int)l, (int)ra, Sm, false);
-            S0 = __builtin_amdgcn_sdot4((int)l, (int)rb, S0, false);
-            Sp = __builtin_amdgcn_sdot4((int)l, (int)rc, Sp, false);
-            rc = rb; rb = ra;
+            for (int i = 0; i <= 2 * R; i++) {
+                const uint32_t ra = prq[i + 2];
+                const uint32_t l = plq[i];
+                Sm = __builtin_amdgcn_sdot4((int)l, (int)ra, Sm, false);
+                S0 = __builtin_amdgcn_sdot4((int)l, (int)rb, S0, false);
+                Sp = __builtin_amdgcn_sdot4((int)l, (int)rc, Sp, false);
+                rc = rb; rb = ra;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i <= 2 * R; i++) {
+                const uint32_t ra = prq[i + 2];
+                const uint32_t l = plq[i] & m;
+                Sm = __builtin_amdgcn_sdot4((int)l, (int)ra, Sm, false);
+                S0 = __builtin_amdgcn_sdot4((int)l, (int)rb, S0, false);
+                Sp = __builtin_amdgcn_sdot4((int)l, (int)rc, Sp, false);
+                rc = rb; rb = ra;
+            }
         }
     }
 
