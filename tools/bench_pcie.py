@@ -1,5 +1,5 @@
 """Host-buffer (PCIe-inclusive) rate of the dense NCC at BASELINE config[1]: mis_upload_pair from
-host rasters, mis_ncc_dense with host outputs.  Reported in DESIGN.md, never as bench.py's value."""
+host rasters, mis_ncc_dense with host outputs.  A side measurement: bench.py reports the device-resident rate."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R + '/image-processing_amd']
