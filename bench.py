@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--disp", type=int, default=256, help="search is +-disp pixels")
     ap.add_argument("--gather", choices=["on", "off"], default="on",
                     help="with N>1: gather disparity/peak rasters to rank 0 (overlapped)")
-    ap.add_argument("--cpu-rows", type=int, default=4096,
+    ap.add_argument("--cpu-rows", type=int, default=8192,
                     help="rows of the frame the CPU oracle is timed on (0: skip the CPU baseline)")
     return ap.parse_args()
 
