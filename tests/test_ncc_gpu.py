@@ -132,3 +132,29 @@ def test_u16_second_peak_is_refused(ctx):
     ctx.upload_pair(left, left)
     with pytest.raises(Exception):
         ctx.ncc_dense(7, -4, 4, want_peak2=True)
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    window = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 21, 25, 29, 31]))
+    h = int(rng.integers(window, window + 70))
+    w = int(rng.integers(window + 2, 420))
+    span = int(rng.choice([1, 2, 5, 33, 64, 65, 68, 100, 129, 200, 300]))
+    dmin = int(rng.integers(-span, 40))
+    dmax = dmin + span - 1
+    dtype = np.uint16 if rng.random() < 0.35 else np.uint8
+    shift = int(rng.integers(dmin - 3, dmax + 4))
+    return window, h, w, dmin, dmax, dtype, shift
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_shapes_windows_and_ranges(ctx, seed):
+    """Random window sizes, frame shapes (down to a single valid row), search ranges (one disparity,
+    ranges that end on / just past a multiple of 64, all-positive or all-negative ranges) and pixel
+    types against the oracle."""
+    window, h, w, dmin, dmax, dtype, shift = _random_case(1000 + seed)
+    left = _texture16(h, w, seed) if dtype == np.uint16 else synth.texture(h, w, seed)
+    right = synth.shift_right_image(left, shift, fill_seed=seed + 500)
+    if seed % 5 == 0:
+        left[h // 3: h // 2, w // 4: w // 2] = left[0, 0]          # a flat patch
+    _run(ctx, left, right, window, dmin, dmax)

@@ -226,3 +226,35 @@ def test_largest_power_of_two_tile_8192(ctx):
     ctx.upload_pair(img1, img2)
     peak, ox, oy = ctx.find_offset((0, 0, 8192, 8192), (0, 0, 8192, 8192), 8192, 8192)
     assert (ox, oy) == (321, -123) and peak == pytest.approx(1.0, abs=1e-4)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_tile_sizes_boxes_and_types(ctx, seed):
+    """Random transform sizes (powers of two and not, odd, rectangular), bounding boxes smaller than the
+    transform or running off the raster, 8/16-bit/float rasters: offsets equal to the oracle's, peak and
+    surfaces within tolerance."""
+    rng = np.random.default_rng(7000 + seed)
+    if seed % 2:
+        w, h = (int(2 ** rng.integers(4, 9)), int(2 ** rng.integers(4, 9)))
+    else:
+        w, h = int(rng.integers(20, 300)), int(rng.integers(20, 300))
+    dx, dy = int(rng.integers(-w // 5, w // 5 + 1)), int(rng.integers(-h // 5, h // 5 + 1))
+    dtype = [np.uint8, np.uint16, np.float32][seed % 3]
+    base1, base2 = _pair(h + 16, w + 16, dx, dy, 900 + seed, np.uint16 if dtype != np.uint8 else np.uint8)
+    img1, img2 = base1.astype(dtype), base2.astype(dtype)
+    b1 = (int(rng.integers(0, 12)), int(rng.integers(0, 12)), int(rng.integers(w // 2, w + 1)), int(rng.integers(h // 2, h + 1)))
+    b2 = (int(rng.integers(0, 12)), int(rng.integers(0, 12)), b1[2], b1[3])
+    if seed % 6 == 0:
+        b1 = (w // 2, h // 2, w, h)                    # runs off the raster on the right / bottom
+    ctx.upload_pair(img1, img2)
+    peak, ox, oy = ctx.find_offset(b1, b2, w, h)
+    ref = oracle.find_offset(img1, img2, b1, b2, w, h, precision=1, want_surface=True, want_dog=True)
+    surf, dog = ctx.tile_surfaces(b1, b2, w, h)
+    assert np.abs(surf - ref["surface"]).max() <= 3e-5
+    assert np.abs(dog - ref["dog"]).max() <= 1e-4
+    if (ox, oy) != (ref["dx"], ref["dy"]):
+        # a different peak position is acceptable only where the two DoG values tie within float noise
+        a = ref["dog"][oy % h, ox % w]
+        assert abs(a - ref["dog_peak"]) <= 2e-5, (ox, oy, ref["dx"], ref["dy"])
+    else:
+        assert abs(peak - ref["peak"]) <= 1e-4 * max(abs(ref["peak"]), 1e-3) + 1e-5
