@@ -62,3 +62,27 @@ def test_empty(ctx):
     c1, c2 = cameras()
     out = ctx.calculate_xyz(mistereo.make_camera(*c1), mistereo.make_camera(*c2), np.zeros((0, 4), np.int32))
     assert out.shape == (0, 3)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_cameras_bit_exact(ctx, seed):
+    """Random intrinsics, rotations up to a few degrees, positions and heights: still bit for bit."""
+    rng = np.random.default_rng(50 + seed)
+    def rot(a):
+        cx, sx, cy, sy, cz, sz = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
+        return (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+                @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    f = float(rng.uniform(3000, 15000))
+    A = [[f, 0, float(rng.uniform(1000, 5000))], [0, f * float(rng.uniform(0.98, 1.02)), float(rng.uniform(1000, 5000))], [0, 0, 1]]
+    R1, R2 = rot(rng.uniform(-0.05, 0.05, 3)), rot(rng.uniform(-0.05, 0.05, 3))
+    hgt = float(rng.uniform(500, 4000))
+    c1 = (A, R1, -R1 @ np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), hgt]))
+    c2 = (A, R2, -R2 @ np.array([rng.uniform(300, 1200), rng.uniform(-50, 50), hgt + rng.uniform(-100, 100)]))
+    n = 1500
+    u1 = rng.integers(0, 8192, n); v1 = rng.integers(0, 8192, n)
+    pts = np.stack([u1, v1, u1 - rng.integers(-600, 601, n), v1 + rng.integers(-3, 4, n)], axis=1).astype(np.int32)
+    got = ctx.calculate_xyz(mistereo.make_camera(*c1), mistereo.make_camera(*c2), pts)
+    want = oracle.triangulate(oracle.make_camera(*c1), oracle.make_camera(*c2), pts)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
