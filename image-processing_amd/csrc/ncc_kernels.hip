@@ -471,6 +471,12 @@ __global__ __launch_bounds__(1024) void ncc_main_kernel(
 __device__ __forceinline__ void ncc_pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void ncc_pin_s(uint32_t& v) { asm volatile("" : "+s"(v)); }
 __device__ __forceinline__ void ncc_pin_s(float& v) { asm volatile("" : "+s"(v)); }
+// (the compiler pads a run of asm statements with a wait state, so the pins of a group come first)
+__device__ __forceinline__ void ncc_pin_b4(float* sv, float* iv, float* cv, float* gv)
+{
+    asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(iv[0]), "+v"(iv[1]), "+v"(iv[2]), "+v"(iv[3]),
+                      "+s"(cv[0]), "+s"(cv[1]), "+s"(cv[2]), "+s"(cv[3]), "+s"(gv[0]), "+s"(gv[1]), "+s"(gv[2]), "+s"(gv[3]));
+}
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 // Argmax kernel: ONE wavefront per workgroup = one chunk of 64 disparities for one strip of WT
@@ -653,12 +659,13 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
                 if (g + 1 < NGA) loadA(lrow, g + 1, set ^ 1);
                 else loadB(ncrow, ngrow, 0, 0);          // unconditional: warm-up rows request row 0's tables and drop them
                 __builtin_amdgcn_sched_barrier(0);
+                static_assert(GB % 4 == 0, "part B pins its values four columns at a time");
+#pragma unroll
+                for (int e = 0; e < GA; e++) { ncc_pin(bv[set][e]); ncc_pin_s(av[set][e]); }
 #pragma unroll
                 for (int e = 0; e < GA; e++) {
                     const int k = GA * g + e;
                     if (k < NCP) {
-                        ncc_pin(bv[set][e]);
-                        ncc_pin_s(av[set][e]);
                         C[k] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, av[set][e]),
                                                       __builtin_bit_cast(half2_t, bv[set][e]), C[k], false);
                     }
@@ -680,28 +687,33 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
                 NCC_WAIT();
                 if (g + 1 < NGB) loadB(ncrow, ngrow, g + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
+                // The packed fmas of the group's column pairs are written interleaved (all tt, then all
+                // cov, then all scores): a dependent v_pk_fma_f32 right behind its producer costs a wait
+                // state, an independent one does not.
+                constexpr int NP = GB / 2;
+                float2_t S2[NP], s2[NP], i2[NP], c2[NP], g2[NP], tt[NP], cov[NP], sc[NP];
 #pragma unroll
-                for (int e = 0; e < GB; e += 2) {
-                    const int j = GB * g + e;
-                    // two columns per packed fma (v_pk_fma_f32)
-                    ncc_pin(sv[set][e]); ncc_pin(sv[set][e + 1]); ncc_pin(iv[set][e]); ncc_pin(iv[set][e + 1]);
-                    ncc_pin_s(cv[set][e]); ncc_pin_s(cv[set][e + 1]); ncc_pin_s(gv[set][e]); ncc_pin_s(gv[set][e + 1]);
-                    const float2_t s2 = { sv[set][e], sv[set][e + 1] }, i2 = { iv[set][e], iv[set][e + 1] };
-                    const float2_t c2 = { cv[set][e], cv[set][e + 1] }, g2 = { gv[set][e], gv[set][e + 1] };
+                for (int e = 0; e < GB; e += 4) ncc_pin_b4(&sv[set][e], &iv[set][e], &cv[set][e], &gv[set][e]);
+#pragma unroll
+                for (int pq = 0; pq < NP; pq++) {
+                    const int e = 2 * pq, j = GB * g + e;
+                    s2[pq] = float2_t{ sv[set][e], sv[set][e + 1] }; i2[pq] = float2_t{ iv[set][e], iv[set][e + 1] };
+                    c2[pq] = float2_t{ cv[set][e], cv[set][e + 1] }; g2[pq] = float2_t{ gv[set][e], gv[set][e + 1] };
                     const float Sa = S + C[j + 2 * R];
                     const float Sb = (Sa - C[j]) + C[j + 1 + 2 * R];
                     S = Sb - C[j + 1];
-                    const float2_t S2 = { Sa, Sb };
-                    const float2_t tt = __builtin_elementwise_fma(c2, s2, S2);       // S - c*S_R, exact
-                    const float2_t cov = __builtin_elementwise_fma(g2, s2, tt);      // - (rem/N)*S_R
-                    const float2_t sc = __builtin_elementwise_fma(cov, i2, bias2);
-                    // the two halves go through pins: this compiler otherwise merges the two key
-                    // computations into one and uses the first column's key for both
-                    float sca = sc.x, scb = sc.y;
-                    ncc_pin(sca); ncc_pin(scb);
-                    tr.push(j & 15, ncc_make_key(sca, tag));
-                    tr.push((j + 1) & 15, ncc_make_key(scb, tag));
+                    S2[pq] = float2_t{ Sa, Sb };
                 }
+#pragma unroll
+                for (int pq = 0; pq < NP; pq++) tt[pq] = __builtin_elementwise_fma(c2[pq], s2[pq], S2[pq]);     // S - c*S_R, exact
+#pragma unroll
+                for (int pq = 0; pq < NP; pq++) cov[pq] = __builtin_elementwise_fma(g2[pq], s2[pq], tt[pq]);    // - (rem/N)*S_R
+#pragma unroll
+                for (int pq = 0; pq < NP; pq++) sc[pq] = __builtin_elementwise_fma(cov[pq], i2[pq], bias2);
+                static_assert(GB % 4 == 0, "columns are keyed four at a time");
+#pragma unroll
+                for (int pq = 0; pq < NP; pq += 2)
+                    tr.push4((GB * g + 2 * pq) & 15, sc[pq].x, sc[pq].y, sc[pq + 1].x, sc[pq + 1].y, tag);
                 if (((GB * (g + 1)) & 15) == 0) q[(GB * g) >> 4] = tr.q;
                 ncc_pin(S);
                 __builtin_amdgcn_sched_barrier(0);

@@ -26,37 +26,63 @@ __device__ __forceinline__ float ncc_make_key(float sc, uint32_t tag)
 
 #define NCC_DPP_MAX(dst, src, mods) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " mods : "+v"(dst) : "v"(src))
 
-__device__ __forceinline__ float vmax_raw(float a, float b)
-{
-    float r;
-    asm volatile("s_nop 1\n\tv_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // NaN operands are ignored
-    return r;
-}
-
 // ---- transposing max network, fed one column at a time ----
+// (a lane swap needs two wait states behind the VALU write of its operands, none in front of the
+// VALU read of its results)
 __device__ __forceinline__ float ncc_merge32(float a, float b)
 {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return vmax_raw(a, b);        // lanes 0-31: column of a, lanes 32-63: column of b
+    float r;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %1, %2\n\tv_max_f32 %0, %1, %2" : "=v"(r), "+v"(a), "+v"(b));
+    return r;                     // lanes 0-31: column of a, lanes 32-63: column of b
 }
 __device__ __forceinline__ float ncc_merge16(float a, float b)
 {
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return vmax_raw(a, b);        // rows 0,2 from a, rows 1,3 from b
+    float r;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %1, %2\n\tv_max_f32 %0, %1, %2" : "=v"(r), "+v"(a), "+v"(b));
+    return r;                     // rows 0,2 from a, rows 1,3 from b
 }
+// Both DPP steps of a merge sit in ONE asm statement: its inputs exist before the statement starts,
+// so the single s_nop 1 (VALU write -> DPP read needs two wait states) covers both reads, and the
+// early-clobber output keeps the result register apart from the inputs.
 __device__ __forceinline__ float ncc_merge8(float a, float b)
 {
-    float o = a;
-    NCC_DPP_MAX(o, a, "row_ror:8 row_mask:0xf bank_mask:0xf");
-    NCC_DPP_MAX(o, b, "row_ror:8 row_mask:0xf bank_mask:0xc");
+    float o;
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(o) : "v"(a), "v"(b));
     return o;                     // lanes 0-7 of every row from a, lanes 8-15 from b
 }
 __device__ __forceinline__ float ncc_merge4(float a, float b)
 {
-    float o = a;
-    NCC_DPP_MAX(o, a, "row_shl:4 row_mask:0xf bank_mask:0x5");
-    NCC_DPP_MAX(o, b, "row_shr:4 row_mask:0xf bank_mask:0xa");
+    float o;
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_max_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(o) : "v"(a), "v"(b));
     return o;                     // banks 0,2 from a, banks 1,3 from b
+}
+
+// Scores of four columns -> keys -> both DPP levels, as one hand-scheduled statement: every DPP read
+// sits at least two instructions behind the write of its source, which leaves a single wait state
+// to pad.  The score registers are overwritten with their keys.
+__device__ __forceinline__ float ncc_quad4(float s0, float s1, float s2, float s3, uint32_t tag)
+{
+    float o0, o1, p;
+    asm volatile("v_and_or_b32 %3, %3, %7, %8\n\t"
+                 "v_and_or_b32 %4, %4, %7, %8\n\t"
+                 "v_and_or_b32 %5, %5, %7, %8\n\t"
+                 "v_and_or_b32 %6, %6, %7, %8\n\t"
+                 "v_max_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_max_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_max_f32_dpp %2, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "s_nop 0\n\t"
+                 "v_max_f32_dpp %2, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(o0), "=&v"(o1), "=&v"(p), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3)
+                 : "s"(0xFFFFFFC0u), "v"(tag));
+    return p;
 }
 
 // Keys of 16 columns (lane = candidate) -> one register in which every 4-lane bank holds the 4
@@ -73,6 +99,15 @@ struct NccTree {
         const float m1 = ncc_merge8(t0, k);
         if ((jj & 2) == 0) { t1 = m1; return; }
         const float m2 = ncc_merge4(t1, m1);
+        if ((jj & 4) == 0) { t2 = m2; return; }
+        const float m3 = ncc_merge32(t2, m2);
+        if ((jj & 8) == 0) { t3 = m3; return; }
+        q = ncc_merge16(t3, m3);
+    }
+    // four columns at once (jj = 0, 4, 8, 12), from their scores
+    __device__ __forceinline__ void push4(int jj, float s0, float s1, float s2, float s3, uint32_t tag)
+    {
+        const float m2 = ncc_quad4(s0, s1, s2, s3, tag);
         if ((jj & 4) == 0) { t2 = m2; return; }
         const float m3 = ncc_merge32(t2, m2);
         if ((jj & 8) == 0) { t3 = m3; return; }
