@@ -80,48 +80,152 @@ __device__ __forceinline__ void ray(const TriCam& c, int u, int v, float* ang)
     }
 }
 
-// image3.cpp:148-264 for one point
-__device__ void triangulate_point(const TriCam& c1, const TriCam& c2, int u1, int v1, int u2, int v2,
-                                  float& X, float& Y, float& Z)
+// ---- the same search, two steps of z per iteration --------------------------------------------
+// The two loops of image3.cpp:220-246 evaluate xyz2 at z0, z0+1, ... about a hundred steps past the
+// minimum, so a point costs 200+ evaluations.  The fast path below produces the same bits with a
+// third of the instructions:
+//  * two consecutive z are evaluated together with packed float32 instructions (each lane of a
+//    packed multiply / add / fma rounds exactly like the scalar one);
+//  * the quotient (w1z - t2z) / ang2z uses the division sequence the compiler emits for a float
+//    division (reciprocal estimate, one Newton step, two residual corrections of the quotient) with
+//    the part that depends on the divisor alone hoisted out of the loops.  That sequence skips the
+//    operand scaling and the special-case fix-up of the general one, which only act on zero, huge,
+//    tiny or non-finite operands: tri_fast_ok() admits the points and cameras whose operands stay
+//    away from those ranges, every other point runs the
+//    loops as written, with general arithmetic;
+//  * the square root is not evaluated per step.  err = sqrtf(s) is only ever compared with the
+//    smallest error so far, E; sqrtf rounds to nearest, so sqrtf(s) < E holds exactly when s lies
+//    below the square of the midpoint between E and the float below it.  That bound is kept as a
+//    float (the largest one below the squared midpoint, which itself is never a float) and is
+//    recomputed, in double, whenever E changes;
+//  * X, Y, Z of the best step are recomputed from its z at the end (they depend on z alone).
+typedef float tri_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float tri_below(float v) { return __uint_as_float(__float_as_uint(v) - 1u); }   // v > 0
+
+// largest float s with sqrtf(s) < E  (NaN when no s qualifies through a NaN E; -1 for E == 0)
+__device__ float tri_bound(float E)
 {
-    float ang1[3], ang2[3];
-    ray(c1, u1, v1, ang1);
-    ray(c2, u2, v2, ang2);
-    const float* t1p = c1.tp;
-    const float* t2p = c2.tp;
-    float X1, Y1, Z1;
-    float z0 = 0.0f;
-    float error0 = xyz2(ang1, t1p, ang2, t2p, z0, X, Y, Z);
-    float z1 = 1000.0f;
-    float error1 = xyz2(ang1, t1p, ang2, t2p, z1, X, Y, Z);
-    z0 = z0 + ((z1 - z0) / (error1 - error0) * (0 - error0));          // image3.cpp:216
-    float min_error = error0;
-    int counter = 0;
-    for (z1 = z0; z1 < t1p[2]; z1 += 1.0f) {                             // image3.cpp:220-232
-        float e = xyz2(ang1, t1p, ang2, t2p, z1, X1, Y1, Z1);
-        if (e < min_error) { counter = 0; min_error = e; X = X1; Y = Y1; Z = Z1; }
-        else if (counter++ > 100) break;
-    }
-    counter = 0;
-    for (z1 = z0; z1 > 0; z1 -= 1.0f) {                                  // image3.cpp:233-246
-        float e = xyz2(ang1, t1p, ang2, t2p, z1, X1, Y1, Z1);
-        if (e < min_error) { counter = 0; min_error = e; X = X1; Y = Y1; Z = Z1; }
-        else if (counter++ > 100) break;
-    }
+    if (E == 0.0f) return -1.0f;
+    const double B = 0.5 * ((double)tri_below(E) + (double)E);
+    const double T = B * B;                                  // exact: B has 25 significant bits
+    float f = (float)T;
+    if ((double)f >= T) f = tri_below(f);
+    return f;
 }
 
-__global__ __launch_bounds__(256) void tri_points_kernel(TriCam c1, TriCam c2, const int4* __restrict__ pts,
-                                                         int n, float* __restrict__ xyz)
+struct TriFast {
+    float a1[3], a2[3];      // ray directions
+    float nb, y;             // -ang2z, refined reciprocal of ang2z
+};
+
+__device__ __forceinline__ tri_f2 tri_s2(const TriFast& r, const float* t1p, const float* t2p, tri_f2 z)
+{
+    const tri_f2 w1x = z * r.a1[0] + t1p[0];
+    const tri_f2 w1y = z * r.a1[1] + t1p[1];
+    const tri_f2 w1z = z * r.a1[2] + t1p[2];
+    const tri_f2 a = w1z - t2p[2];
+    const tri_f2 nb = { r.nb, r.nb }, y = { r.y, r.y };
+    const tri_f2 q0 = a * y;
+    const tri_f2 r0 = __builtin_elementwise_fma(nb, q0, a);
+    const tri_f2 q1 = __builtin_elementwise_fma(r0, y, q0);
+    const tri_f2 r1 = __builtin_elementwise_fma(nb, q1, a);
+    const tri_f2 z2 = __builtin_elementwise_fma(r1, y, q1);
+    const tri_f2 w2x = z2 * r.a2[0] + t2p[0];
+    const tri_f2 w2y = z2 * r.a2[1] + t2p[1];
+    const tri_f2 dx = w1x - w2x, dy = w1y - w2y;
+    return dx * dx + dy * dy;
+}
+
+// cameras whose heights keep the quotient's operands in the plain range of the division sequence
+static bool tri_cams_fast(const TriCam& c1, const TriCam& c2)
+{
+    const float lo = 9.5367431640625e-07f, hi = 1048576.0f;        // 2^-20, 2^20
+    const float t1 = fabsf(c1.tp[2]), t2 = fabsf(c2.tp[2]);
+    return t1 <= hi && t2 >= lo && t2 <= hi;                        // false for NaN
+}
+__device__ __forceinline__ bool tri_fast_ok(float ang1z, float ang2z, float z0)
+{
+    const float lo = 9.5367431640625e-07f, hi = 1048576.0f;
+    const float b = fabsf(ang2z);
+    return b >= lo && b <= hi && fabsf(ang1z) <= hi && fabsf(z0) <= 4.0f * hi;   // false for NaN
+}
+
+// image3.cpp:148-264 for one point
+__device__ void triangulate_point(const TriCam& c1, const TriCam& c2, bool cams_fast,
+                                       int u1, int v1, int u2, int v2, float& X, float& Y, float& Z)
+{
+    TriFast r;
+    ray(c1, u1, v1, r.a1);
+    ray(c2, u2, v2, r.a2);
+    const float* t1p = c1.tp;
+    const float* t2p = c2.tp;
+    float z0 = 0.0f;
+    const float error0 = xyz2(r.a1, t1p, r.a2, t2p, z0, X, Y, Z);
+    float z1 = 1000.0f;
+    const float error1 = xyz2(r.a1, t1p, r.a2, t2p, z1, X, Y, Z);
+    z0 = z0 + ((z1 - z0) / (error1 - error0) * (0 - error0));          // image3.cpp:216
+    if (!(cams_fast && tri_fast_ok(r.a1[2], r.a2[2], z0))) {
+        // same search, general arithmetic
+        float X1, Y1, Z1, min_error = error0;
+        int counter = 0;
+        for (z1 = z0; z1 < t1p[2]; z1 += 1.0f) {
+            float e = xyz2(r.a1, t1p, r.a2, t2p, z1, X1, Y1, Z1);
+            if (e < min_error) { counter = 0; min_error = e; X = X1; Y = Y1; Z = Z1; }
+            else if (counter++ > 100) break;
+        }
+        counter = 0;
+        for (z1 = z0; z1 > 0; z1 -= 1.0f) {
+            float e = xyz2(r.a1, t1p, r.a2, t2p, z1, X1, Y1, Z1);
+            if (e < min_error) { counter = 0; min_error = e; X = X1; Y = Y1; Z = Z1; }
+            else if (counter++ > 100) break;
+        }
+        return;
+    }
+    {
+        const float b = r.a2[2];
+        const float rc = __builtin_amdgcn_rcpf(b);
+        const float e0 = fmaf(-b, rc, 1.0f);
+        r.y = fmaf(e0, rc, rc);
+        r.nb = -b;
+    }
+    float zbest = 1000.0f;              // X, Y, Z hold the z = 1000 evaluation until a step improves on error0
+    float bound = tri_bound(error0);
+    const float lim = t1p[2];
+    for (int dir = 0; dir < 2; dir++) {
+        const float step = dir ? -1.0f : 1.0f;
+        int counter = 0;
+        tri_f2 z = { z0, z0 + step };
+        for (;;) {
+            if (dir ? !(z.x > 0) : !(z.x < lim)) break;
+            const tri_f2 s = tri_s2(r, t1p, t2p, z);
+            if (s.x <= bound) { counter = 0; zbest = z.x; bound = tri_bound(sqrtf(s.x)); }
+            else if (counter++ > 100) break;
+            if (dir ? !(z.y > 0) : !(z.y < lim)) break;
+            if (s.y <= bound) { counter = 0; zbest = z.y; bound = tri_bound(sqrtf(s.y)); }
+            else if (counter++ > 100) break;
+            z = (z + step) + step;
+        }
+    }
+    X = zbest * r.a1[0] + t1p[0];
+    Y = zbest * r.a1[1] + t1p[1];
+    Z = zbest * r.a1[2] + t1p[2];
+}
+
+__global__ __launch_bounds__(256) void tri_points_kernel(TriCam c1, TriCam c2, bool cams_fast,
+                                                         const int4* __restrict__ pts, int n, float* __restrict__ xyz)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int4 p = pts[i];
     float X, Y, Z;
-    triangulate_point(c1, c2, p.x, p.y, p.z, p.w, X, Y, Z);
+    triangulate_point(c1, c2, cams_fast, p.x, p.y, p.z, p.w, X, Y, Z);
     xyz[3 * (size_t)i] = X; xyz[3 * (size_t)i + 1] = Y; xyz[3 * (size_t)i + 2] = Z;
 }
 
-__global__ __launch_bounds__(256) void tri_disparity_kernel(TriCam c1, TriCam c2, const float* __restrict__ disp,
+#define TRI_COUNT_SLOTS 64
+__global__ __launch_bounds__(256) void tri_disparity_kernel(TriCam c1, TriCam c2, bool cams_fast,
+                                                            const float* __restrict__ disp,
                                                             const float* __restrict__ peak, float min_peak,
                                                             int W, int H, float* __restrict__ xyz,
                                                             unsigned long long* __restrict__ count)
@@ -136,12 +240,22 @@ __global__ __launch_bounds__(256) void tri_disparity_kernel(TriCam c1, TriCam c2
         ok = (d != (float)MIS_INVALID_DISP) && (peak[o] >= min_peak);
         if (ok) {
             int u2 = x - (int)rintf(d);
-            triangulate_point(c1, c2, x, y, u2, y, X, Y, Z);
+            triangulate_point(c1, c2, cams_fast, x, y, u2, y, X, Y, Z);
         }
         xyz[3 * o] = X; xyz[3 * o + 1] = Y; xyz[3 * o + 2] = Z;
     }
-    unsigned long long m = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+    // One atomic per workgroup, spread over TRI_COUNT_SLOTS counters in separate 128-byte lines: a
+    // single device-wide counter serialises about a million same-address atomics per frame in the
+    // memory system and ends up longer than the arithmetic.
+    __shared__ unsigned s_cnt[4];
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) % TRI_COUNT_SLOTS;
+        if (n) atomicAdd(count + slot * 16, (unsigned long long)n);
+    }
 }
 
 static int tri_check(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2)
@@ -163,7 +277,7 @@ int mis_triangulate_device(mis_ctx* ctx, const mis_camera* c1, const mis_camera*
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     TriCam a = make_cam(c1), b = make_cam(c2);
     hipLaunchKernelGGL(tri_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a, b,
-                       (const int4*)d_pts, n, d_xyz);
+                       tri_cams_fast(a, b), (const int4*)d_pts, n, d_xyz);
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
@@ -198,20 +312,23 @@ int mis_triangulate_disparity_device(mis_ctx* ctx, const mis_camera* c1, const m
     if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "triangulate: no image pair bound (raster size unknown)");
     if (!d_disp || !d_peak || !d_xyz) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: NULL buffer");
     MIS_HIP(ctx, hipSetDevice(ctx->device));
-    rc = mis_reserve(ctx, &ctx->tri_buf, &ctx->tri_bytes, 256);
+    const size_t cnt_bytes = (size_t)TRI_COUNT_SLOTS * 128;
+    rc = mis_reserve(ctx, &ctx->tri_buf, &ctx->tri_bytes, cnt_bytes);
     if (rc) return rc;
     unsigned long long* cnt = (unsigned long long*)ctx->tri_buf;
-    MIS_HIP(ctx, hipMemsetAsync(cnt, 0, 256, ctx->stream));
+    MIS_HIP(ctx, hipMemsetAsync(cnt, 0, cnt_bytes, ctx->stream));
     TriCam a = make_cam(c1), b = make_cam(c2);
     const int W = ctx->width, H = ctx->height;
     hipLaunchKernelGGL(tri_disparity_kernel, dim3((W + 255) / 256, H), dim3(256), 0, ctx->stream, a, b,
-                       d_disp, d_peak, min_peak, W, H, d_xyz, cnt);
+                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, W, H, d_xyz, cnt);
     MIS_HIP(ctx, hipGetLastError());
     if (n_matched) {
-        unsigned long long h = 0;
-        MIS_HIP(ctx, hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long h[TRI_COUNT_SLOTS * 16];
+        MIS_HIP(ctx, hipMemcpyAsync(h, cnt, cnt_bytes, hipMemcpyDeviceToHost, ctx->stream));
         MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        *n_matched = (long long)h;
+        unsigned long long total = 0;
+        for (int i = 0; i < TRI_COUNT_SLOTS; i++) total += h[i * 16];
+        *n_matched = (long long)total;
     }
     return MIS_OK;
 }

@@ -86,3 +86,36 @@ def test_random_cameras_bit_exact(ctx, seed):
     nan = np.isnan(want)
     assert np.array_equal(np.isnan(got), nan)
     assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+
+
+@pytest.mark.parametrize("h1,h2", [(0.0, 0.0), (3.0e6, 3.0e6), (3000.0, 0.0), (3000.0, 2.0e-7)])
+def test_cameras_outside_the_fast_range(ctx, h1, h2):
+    """Camera heights of zero, tiny or beyond 2^20 make the library run the search with general
+    division and square roots instead of its hoisted-reciprocal path: same bits either way."""
+    A = [[10000, 0, 4096], [0, 10000, 4096], [0, 0, 1]]
+    R = np.eye(3)
+    c1 = (A, R, -R @ np.array([0.0, 0.0, h1]))
+    c2 = (A, R, -R @ np.array([900.0, 0.0, h2]))
+    rng = np.random.default_rng(7)
+    n = 600
+    u1 = rng.integers(0, 8192, n); v1 = rng.integers(0, 8192, n)
+    pts = np.stack([u1, v1, u1 - rng.integers(-400, 401, n), v1 + rng.integers(-2, 3, n)], axis=1).astype(np.int32)
+    got = ctx.calculate_xyz(mistereo.make_camera(*c1), mistereo.make_camera(*c2), pts)
+    want = oracle.triangulate(oracle.make_camera(*c1), oracle.make_camera(*c2), pts)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+
+
+def test_many_points_bit_exact(ctx):
+    """A larger sample (a million points, fractional camera parameters) through the two-step search."""
+    c1, c2 = rotated_cameras()
+    rng = np.random.default_rng(11)
+    n = 1_000_000
+    u1 = rng.integers(0, 8192, n); v1 = rng.integers(0, 8192, n)
+    pts = np.stack([u1, v1, u1 - rng.integers(-600, 601, n), v1 + rng.integers(-3, 4, n)], axis=1).astype(np.int32)
+    got = ctx.calculate_xyz(mistereo.make_camera(*c1), mistereo.make_camera(*c2), pts)
+    want = oracle.triangulate(oracle.make_camera(*c1), oracle.make_camera(*c2), pts)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
