@@ -1,0 +1,110 @@
+// Throughput of single vector instructions on one SIMD (cycles per wave64 instruction) with W waves
+// resident per SIMD: each wave runs ITER x 16 independent copies of the instruction and stamps
+// s_memtime around them.  Usage: valu_rates [waves_per_simd]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define ITER 8000
+#define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+template <int OP>
+__global__ __launch_bounds__(64) void k(long long* out, float seed)
+{
+    float r[16]; float b = seed + threadIdx.x, c = seed * 0.5f;
+    double dr[16]; double db = b, dc = c;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { r[i] = seed + i; dr[i] = seed + i; }
+    unsigned sm = 0xFFFFFFC0u; double dsg = 1.5;
+    long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; it++) {
+#define FMA(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(r[i]) : "v"(b), "v"(c));
+#define ADD(i) asm volatile("v_add_f32 %0, %1, %0" : "+v"(r[i]) : "v"(b));
+#define PKF(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dr[i]) : "v"(db), "v"(dc));
+#define PKA(i) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(dr[i]) : "v"(db));
+#define DOT(i) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(r[i]) : "v"(b), "v"(c));
+#define DPP(i) asm volatile("v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(r[i]) : "v"(b));
+#define AOR(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r[i]) : "s"(sm), "v"(b));
+#define SWP(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[(i + 1) & 15]));
+#define CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(b));
+#define F64(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(dr[i]) : "v"(db), "v"(dc));
+#define MUL(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define CVT(i) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(dr[i]) : "v"(b));
+#define D4(i)  asm volatile("v_dot4_i32_i8 %0, %1, %2, %0" : "+v"(r[i]) : "v"(b), "v"(c));
+#define MAX(i) asm volatile("v_max_f32 %0, %1, %0" : "+v"(r[i]) : "v"(b));
+#define SW16(i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[(i + 1) & 15]));
+#define SUBV(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define MULV(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define ADDS(i) asm volatile("v_add_f32 %0, %1, %0" : "+v"(r[i]) : "s"(sm));
+#define FMAN(i) asm volatile("v_fma_f32 %0, %1, -1.0, %0" : "+v"(r[i]) : "v"(b));
+#define ADDN(i) asm volatile("v_add_f32_e64 %0, %0, -%1" : "+v"(r[i]) : "v"(b));
+#define ADDU(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define MOVV(i) asm volatile("v_mov_b32 %0, %1" : "=v"(r[i]) : "v"(b));
+#define FMAS(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(r[i]) : "s"(sm), "v"(c));
+#define FMAC(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(r[i]) : "v"(b), "v"(c));
+#define AORV(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(c), "v"(b));
+#define ANDV(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define ORV(i) asm volatile("v_or_b32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define MAXI(i) asm volatile("v_max_i32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define MAXU(i) asm volatile("v_max_u32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define MINF(i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define MAX3(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(b), "v"(c));
+#define PKFS(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dr[i]) : "s"(dsg), "v"(dc));
+#define PKM(i) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(dr[i]) : "v"(db));
+#define BFI(i) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(r[i]) : "v"(c), "v"(b));
+#define LSO(i) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(r[i]) : "v"(b));
+#define CVTI(i) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(r[i]) : "v"(b));
+#define DOT3(i) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(r[i]) : "v"(b), "v"(c));
+#define XORV(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+#define LSHL(i) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(r[i]));
+#define SUBS(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(r[i]) : "s"(sm));
+        if (OP == 0) { REP16(FMA) } if (OP == 1) { REP16(ADD) } if (OP == 2) { REP16(PKF) } if (OP == 3) { REP16(PKA) }
+        if (OP == 4) { REP16(DOT) } if (OP == 5) { REP16(DPP) } if (OP == 6) { REP16(AOR) } if (OP == 7) { REP16(SWP) }
+        if (OP == 8) { REP16(CND) } if (OP == 9) { REP16(F64) } if (OP == 10) { REP16(MUL) } if (OP == 11) { REP16(CVT) }
+        if (OP == 16) { REP16(SUBV) } if (OP == 17) { REP16(MULV) } if (OP == 18) { REP16(ADDS) } if (OP == 19) { REP16(FMAN) } if (OP == 20) { REP16(ADDN) } if (OP == 21) { REP16(ADDU) } if (OP == 22) { REP16(MOVV) } if (OP == 23) { REP16(FMAS) } if (OP == 24) { REP16(FMAC) }
+        if (OP == 25) { REP16(AORV) } if (OP == 26) { REP16(ANDV) } if (OP == 27) { REP16(ORV) } if (OP == 28) { REP16(MAXI) } if (OP == 29) { REP16(MAXU) } if (OP == 30) { REP16(MINF) } if (OP == 31) { REP16(MAX3) } if (OP == 32) { REP16(PKFS) } if (OP == 33) { REP16(PKM) } if (OP == 34) { REP16(BFI) } if (OP == 35) { REP16(LSO) } if (OP == 36) { REP16(CVTI) } if (OP == 37) { REP16(DOT3) } if (OP == 38) { REP16(XORV) } if (OP == 39) { REP16(LSHL) }
+        if (OP == 12) { REP16(D4) } if (OP == 13) { REP16(MAX) } if (OP == 14) { REP16(SW16) } if (OP == 15) { REP16(SUBS) }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float s = 0; double ds = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { s += r[i]; ds += dr[i]; }
+    if (s + (float)ds == 12345.678f) out[0] = 1;
+    if (threadIdx.x == 0) out[1 + blockIdx.x] = t1 - t0;
+}
+
+template <int OP> void run(const char* name, int wps, long long* d)
+{
+    const int nblk = 256 * 4 * wps;           // one wave per block; wps waves per SIMD when evenly spread
+    std::vector<long long> h(nblk + 1);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(nblk), dim3(64), 0, 0, d, 1.0f);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(nblk), dim3(64), 0, 0, d, 1.0f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h.data(), d, (nblk + 1) * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin() + 1, h.end());
+    const double med = (double)h[1 + nblk / 2], n = (double)ITER * 16;
+    // per-wave cycles per instruction, and SIMD cycles per instruction assuming wps waves share the SIMD
+    printf("%-22s wave: %6.2f cyc/instr   SIMD: %5.2f cyc/instr   (kernel %.3f ms => %.2f ns/instr/SIMD)\n", name, med / n, med / n / wps,
+           ms, ms * 1e6 / (n * wps));
+}
+
+int main(int argc, char** argv)
+{
+    const int wps = argc > 1 ? atoi(argv[1]) : 8;
+    long long* d; hipMalloc(&d, (256 * 4 * 16 + 1) * 8); hipMemset(d, 0, 8);
+    printf("waves per SIMD: %d (s_memtime ticks at a fixed 100 MHz on this part if the cyc columns look 24x small)\n", wps);
+    for (int rep = 0; rep < 2; rep++) {
+        run<0>("v_fma_f32", wps, d); run<13>("v_max_f32", wps, d);
+        run<25>("v_and_or_b32 vgpr", wps, d); run<26>("v_and_b32", wps, d); run<27>("v_or_b32", wps, d); run<38>("v_xor_b32", wps, d); run<39>("v_lshlrev_b32", wps, d);
+        run<28>("v_max_i32", wps, d); run<29>("v_max_u32", wps, d); run<30>("v_min_f32", wps, d); run<31>("v_max3_f32", wps, d);
+        run<2>("v_pk_fma_f32 vgpr", wps, d); run<32>("v_pk_fma_f32 sgpr", wps, d); run<33>("v_pk_mul_f32", wps, d);
+        run<34>("v_bfi_b32", wps, d); run<35>("v_lshl_or_b32", wps, d); run<36>("v_cvt_f32_i32", wps, d); run<37>("v_dot2_f32_f16", wps, d);
+        run<4>("v_dot2c_f32_f16", wps, d);
+    }
+    return 0;
+}
