@@ -41,7 +41,43 @@ struct NccWs {
     int pitch = 0, rows = 0;
     uint64_t pair_serial = 0;   // tables valid for this pair ...
     int window = 0;             // ... and this window
+    // Second stream of the fast path: the small kernels nothing waits for until the refinement
+    // (vertical packs, frame border, tail disparities) run beside the argmax kernel instead of in
+    // front of it.  ev_fork orders the side stream behind the main one, ev_tables behind the tables,
+    // ev_join the refinement behind the side stream.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_tables = nullptr, ev_join = nullptr;
+    bool forked = false;        // the side stream carries work of the current call
 };
+
+// side stream of the current call (created on first use), ordered behind everything enqueued on the main stream so far
+static int ncc_fork(mis_ctx* ctx, NccWs* w)
+{
+    if (w->forked) return MIS_OK;
+    if (!w->side) {
+        // highest priority: its few workgroups are dispatched as soon as wave slots free up, so the
+        // side work ends long before the argmax kernel does
+        int prio_lo = 0, prio_hi = 0;
+        MIS_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        MIS_HIP(ctx, hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, prio_hi));
+        MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+        MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_tables, hipEventDisableTiming));
+        MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
+    }
+    MIS_HIP(ctx, hipEventRecord(w->ev_fork, ctx->stream));
+    MIS_HIP(ctx, hipStreamWaitEvent(w->side, w->ev_fork, 0));
+    w->forked = true;
+    return MIS_OK;
+}
+// main stream waits for the side stream's work of this call
+static int ncc_join(mis_ctx* ctx, NccWs* w)
+{
+    if (!w->forked) return MIS_OK;
+    w->forked = false;
+    MIS_HIP(ctx, hipEventRecord(w->ev_join, w->side));
+    MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, w->ev_join, 0));
+    return MIS_OK;
+}
 
 void mis_ncc_release(mis_ctx* ctx)
 {
@@ -49,6 +85,11 @@ void mis_ncc_release(mis_ctx* ctx)
     if (!w) return;
     void* bufs[] = { w->Lpack, w->negc, w->negg, w->iL, w->Rpack, w->Rsr, w->Rir, w->VL, w->VR, w->keys };
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (w->side) {
+        (void)hipStreamSynchronize(w->side);
+        (void)hipEventDestroy(w->ev_fork); (void)hipEventDestroy(w->ev_tables); (void)hipEventDestroy(w->ev_join);
+        (void)hipStreamDestroy(w->side);
+    }
     delete w;
     ctx->ncc = nullptr;
 }
@@ -744,17 +785,26 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
 // over the nt <= NCC_TAIL_MAX disparities.  Column sums slide down a band of rows in registers
 // (the same v_dot2c on the packed row pairs), the horizontal window sum goes through LDS.  Output:
 // one more key plane in the format of the argmax kernel (plane `chunk`, tags relative to it).
+// The kernel runs beside the argmax kernel on a second stream.  Its workgroups are three wavefronts
+// (192 - 2R output columns): a workgroup can only start on a CU with that many wave slots free at
+// once, and while the argmax grid lasts slots free up one wavefront at a time.  Measured step times
+// at 8192x8192, +-256: 64 threads 16.27 ms (fits anywhere, but a third of its lanes are halo),
+// 128: 15.95, 192: 15.93, 320: 16.05 (mostly runs after the argmax kernel); 16.40 with the tail in
+// front of the argmax kernel on one stream.
 #define NCC_TAIL_MAX 4
-#define NCC_TAIL_TW 256
+#ifndef NCC_TAIL_NT
+#define NCC_TAIL_NT 192
+#endif
+#define NCC_TAIL_TW(RR) (NCC_TAIL_NT - 2 * (RR))
 #define NCC_TAIL_RB 4        // rows whose operands are fetched together (one memory round trip per batch)
 template <int R>
-__global__ __launch_bounds__(320) void ncc_tail_kernel(
+__global__ __launch_bounds__(NCC_TAIL_NT) void ncc_tail_kernel(
     NccArgs a, int d0, int nt, int chunk,
     const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
     const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr, const float* __restrict__ gRir,
     float* __restrict__ oKeys)
 {
-    constexpr int WN = 2 * R + 1, TW = NCC_TAIL_TW, NCOL = TW + 2 * R, RB = NCC_TAIL_RB;
+    constexpr int WN = 2 * R + 1, TW = NCC_TAIL_TW(R), NCOL = TW + 2 * R, RB = NCC_TAIL_RB;
     __shared__ float sC[RB][NCC_TAIL_MAX][NCOL + 2];
     const int tid = threadIdx.x;
     const int x0 = R + blockIdx.x * TW;               // first output column of the workgroup
@@ -1004,10 +1054,9 @@ __global__ __launch_bounds__(256) void ncc_border_kernel(float* disp, float* pea
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
-static int ncc_prepare(mis_ctx* ctx, int window)
+static int ncc_prepare(mis_ctx* ctx, int window, bool use_side)
 {
     NccWs* w = ctx->ncc;
-    if (!w) { w = new NccWs(); ctx->ncc = w; }
     const int W = ctx->width, H = ctx->height, r = window / 2;
     const int pitch = ((W + 64 + 63) / 64) * 64 + 64;   // room for one strip past the right edge
     const size_t npx = (size_t)pitch * H;
@@ -1028,7 +1077,12 @@ static int ncc_prepare(mis_ctx* ctx, int window)
     w->pitch = pitch; w->rows = H;
     dim3 block(256);
     dim3 sgrid((pitch + 255) / 256, (H + NCC_STATS_BAND - 1) / NCC_STATS_BAND);
-    hipStream_t s = ctx->stream;
+    hipStream_t s = ctx->stream, sv = ctx->stream;       // sv: the vertical packs, which only the refinement reads
+    if (use_side) {
+        int rc = ncc_fork(ctx, w);
+        if (rc) return rc;
+        sv = w->side;
+    }
     for (int side = 0; side < 2; side++) {
         const void* img = ctx->img[side];
         if (ctx->dtype == MIS_U8) {
@@ -1039,7 +1093,7 @@ static int ncc_prepare(mis_ctx* ctx, int window)
             else
                 hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, false>), sgrid, block, 0, s, p, ctx->stride, W, H, r, pitch,
                                    w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
-            hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, dim3((pitch + 255) / 256, (H + 3) / 4), block, 0, s, p, ctx->stride,
+            hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, dim3((pitch + 255) / 256, (H + 3) / 4), block, 0, sv, p, ctx->stride,
                                W, H, pitch, side == 0 ? w->VL : w->VR);
         } else {
             return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: only 8-bit rasters are supported by this build");
@@ -1087,18 +1141,24 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     a.nstrips = (a.W - 2 * R + WT - 1) / WT;
     a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
     if (tail) a.nchunk = nfull;
-    // the tail writes its own key plane; it runs first so that the profile marks bracket the argmax kernel alone
+    mis_prof_mark(ctx);                            // tables done
+    // the tail writes its own key plane, beside the argmax kernel (side stream, behind the tables)
     if (tail) {
+        rc = ncc_fork(ctx, w);
+        if (rc) return rc;
+        MIS_HIP(ctx, hipEventRecord(w->ev_tables, ctx->stream));
+        MIS_HIP(ctx, hipStreamWaitEvent(w->side, w->ev_tables, 0));
         NccArgs ta = a;                              // shorter bands: the tail walk is latency bound and wants more workgroups
         ta.band_rows = 64;
         ta.nbands = (a.row1 - a.row0 + ta.band_rows - 1) / ta.band_rows;
-        hipLaunchKernelGGL(ncc_tail_kernel<R>, dim3((a.W - 2 * R + NCC_TAIL_TW - 1) / NCC_TAIL_TW, ta.nbands), dim3(320), 0, ctx->stream,
+        hipLaunchKernelGGL(ncc_tail_kernel<R>, dim3((a.W - 2 * R + NCC_TAIL_TW(R) - 1) / NCC_TAIL_TW(R), ta.nbands), dim3(NCC_TAIL_NT), 0, w->side,
                            ta, a.dmin + nfull * 64, rem, nfull, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
     }
-    mis_prof_mark(ctx);                            // tables (and tail) done
     hipLaunchKernelGGL((ncc_argmax_kernel<R, WT, MW>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
                        a, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
     mis_prof_mark(ctx);
+    rc = ncc_join(ctx, w);                         // vertical packs, border, tail
+    if (rc) return rc;
     {
         const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
         if (lds > 64 * 1024)
@@ -1126,9 +1186,18 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     if (nrows == 0) return MIS_OK;
 
     mis_prof_mark(ctx);
+    // 8-bit pairs without the second-peak output take the fast path, which runs its small kernels on a second stream
+    const bool fast = (ctx->dtype == MIS_U8 && !d_peak2 && W >= window && H >= window);
+    if (fast && !ctx->ncc) ctx->ncc = new NccWs();
     {   // frame border
+        hipStream_t sb = ctx->stream;
+        if (fast) {
+            int rcf = ncc_fork(ctx, ctx->ncc);
+            if (rcf) return rcf;
+            sb = ctx->ncc->side;
+        }
         dim3 grid((W + 255) / 256, nrows), block(256);
-        hipLaunchKernelGGL(ncc_border_kernel, grid, block, 0, ctx->stream, d_disp, d_peak, d_idisp, d_peak2, W, H, r, row0, row0 + nrows);
+        hipLaunchKernelGGL(ncc_border_kernel, grid, block, 0, sb, d_disp, d_peak, d_idisp, d_peak2, W, H, r, row0, row0 + nrows);
     }
     if (W < window || H < window) { mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
     if (ctx->dtype == MIS_U16) {
@@ -1147,8 +1216,9 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     }
     if (ctx->dtype != MIS_U8)
         return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: 8-bit and 16-bit rasters only");
-    int rc = ncc_prepare(ctx, window);
-    if (rc) return rc;
+    if (!ctx->ncc) ctx->ncc = new NccWs();
+    int rc = ncc_prepare(ctx, window, fast);
+    if (rc) { (void)ncc_join(ctx, ctx->ncc); return rc; }
 
     NccWs* w = ctx->ncc;
     NccArgs a;
@@ -1158,7 +1228,7 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     a.row1 = (row0 + nrows < H - r) ? row0 + nrows : H - r;
     a.out_pitch = W;
     a.nstrips = a.nbands = 0;
-    if (a.row0 >= a.row1) { mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
+    if (a.row0 >= a.row1) { mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx); return ncc_join(ctx, w); }
     const int nd = dmax - dmin + 1;
     const int total_chunks = (nd + 63) / 64;
     a.band_rows = 128;
@@ -1178,6 +1248,10 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
         default: rc = mis_fail(ctx, MIS_ERR_ARG, "dense NCC: unsupported window %d", window);
     }
 #undef NCC_CASE
+    if (w->forked) {                               // a failed launch path: leave no work behind on the side stream
+        const int rcj = ncc_join(ctx, w);
+        if (!rc) rc = rcj;
+    }
     mis_prof_mark(ctx);
     return rc;
 }
