@@ -1077,28 +1077,27 @@ static int ncc_prepare(mis_ctx* ctx, int window, bool use_side)
     w->pitch = pitch; w->rows = H;
     dim3 block(256);
     dim3 sgrid((pitch + 255) / 256, (H + NCC_STATS_BAND - 1) / NCC_STATS_BAND);
-    hipStream_t s = ctx->stream, sv = ctx->stream;       // sv: the vertical packs, which only the refinement reads
+    hipStream_t s = ctx->stream, sv = ctx->stream;       // sv: side stream when there is one
     if (use_side) {
         int rc = ncc_fork(ctx, w);
         if (rc) return rc;
         sv = w->side;
     }
-    for (int side = 0; side < 2; side++) {
-        const void* img = ctx->img[side];
-        if (ctx->dtype == MIS_U8) {
-            const uint8_t* p = (const uint8_t*)img;
-            if (side == 0)
-                hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, true>), sgrid, block, 0, s, p, ctx->stride, W, H, r, pitch,
-                                   w->Lpack, w->negc, w->negg, w->iL);
-            else
-                hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, false>), sgrid, block, 0, s, p, ctx->stride, W, H, r, pitch,
-                                   w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
-            hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, dim3((pitch + 255) / 256, (H + 3) / 4), block, 0, sv, p, ctx->stride,
-                               W, H, pitch, side == 0 ? w->VL : w->VR);
-        } else {
-            return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: only 8-bit rasters are supported by this build");
-        }
-    }
+    if (ctx->dtype != MIS_U8)
+        return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: only 8-bit rasters are supported by this build");
+    const uint8_t* pl = (const uint8_t*)ctx->img[0];
+    const uint8_t* pr = (const uint8_t*)ctx->img[1];
+    // the two table kernels run side by side (each alone leaves wave slots idle); the main stream
+    // then waits for the right image's tables only, not for the vertical packs queued behind them
+    hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, false>), sgrid, block, 0, sv, pr, ctx->stride, W, H, r, pitch,
+                       w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
+    if (use_side) MIS_HIP(ctx, hipEventRecord(w->ev_tables, w->side));
+    hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, true>), sgrid, block, 0, s, pl, ctx->stride, W, H, r, pitch,
+                       w->Lpack, w->negc, w->negg, w->iL);
+    if (use_side) MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, w->ev_tables, 0));
+    const dim3 vgrid((pitch + 255) / 256, (H + 3) / 4);
+    hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, vgrid, block, 0, sv, pl, ctx->stride, W, H, pitch, w->VL);
+    hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, vgrid, block, 0, sv, pr, ctx->stride, W, H, pitch, w->VR);
     MIS_HIP(ctx, hipGetLastError());
     w->pair_serial = ctx->pair_serial;
     w->window = window;
