@@ -96,17 +96,54 @@ static int ensure_ws(mis_ctx* ctx)
 // back (sequence s occupies x[s*n .. s*n+n)).  All threads of the workgroup take part; the caller
 // has synchronised before the call, and the routines end with a barrier.
 // tw: n/2 values exp(-2 pi i k / n).
+// NT: threads of the workgroup, a template parameter here and a literal in the kernels below
+// (every kernel is launched with exactly its __launch_bounds__): blockDim.x is a load from the
+// dispatch packet, a memory round trip the compiler repeats in every pass.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// Keeps every element of v[] behind this point: loads issued above cannot be moved (back) into the
+// conditional blocks below, where the compiler would wait for each one separately.
+template <int U>
+__device__ __forceinline__ void pin_loaded(float4 (&v)[U])
+{
+#pragma unroll
+    for (int u = 0; u < U; u++) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+}
+
+// Contiguous global -> LDS copy of n float2 (n even, 16-byte aligned on both sides) by an NT-thread
+// workgroup: 16-byte loads, U of them in flight per thread (clamped addresses, tested stores).
+template <int NT, int U>
+__device__ __forceinline__ void stage_contiguous(float2* dst, const float2* __restrict__ src, int n)
+{
+    if (n & 1) {                                     // degenerate sizes only
+        for (int i = threadIdx.x; i < n; i += NT) dst[i] = src[i];
+        return;
+    }
+    const int n4 = n >> 1;
+    const float4* s4 = (const float4*)src;
+    float4* d4 = (float4*)dst;
+    for (int base = 0; base < n4; base += NT * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = s4[min(base + (int)threadIdx.x + NT * u, n4 - 1)];
+        pin_loaded(v);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + (int)threadIdx.x + NT * u;
+            if (i < n4) d4[i] = v[u];
+        }
+    }
+}
+
 // Up to three consecutive radix-2 stages are done in registers by the thread that owns the 2^S
 // elements they connect (indices base + m * 2^l_lo, m = 0 .. 2^S - 1): the arithmetic is exactly
 // that of S radix-2 passes, with a third of the LDS traffic and barriers.
 // Stage with half = 2^l: butterfly (i, i + half), twiddle index (i mod half) << (logn - 1 - l).
-template <int S>
+template <int S, int NT>
 __device__ __forceinline__ void fft_dif_pass(float2* x, int logn, int cnt, int l_hi, const float2* __restrict__ tw)
 {
     constexpr int M = 1 << S;
@@ -114,7 +151,7 @@ __device__ __forceinline__ void fft_dif_pass(float2* x, int logn, int cnt, int l
     const int n = 1 << logn;
     const int gps = n >> S;                        // groups per sequence
     const int groups = cnt * gps;
-    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+    for (int g = threadIdx.x; g < groups; g += NT) {
         const int seq = g / gps, gi = g - seq * gps;
         const int low = gi & ((1 << l_lo) - 1), high = gi >> l_lo;
         const int i0 = (high << (l_hi + 1)) + low;            // index of element m = 0 inside the sequence
@@ -143,17 +180,18 @@ __device__ __forceinline__ void fft_dif_pass(float2* x, int logn, int cnt, int l
 }
 
 // forward (sign -1), decimation in frequency: natural order in, bit-reversed order out
+template <int NT>
 __device__ void fft_dif_fwd(float2* x, int logn, int cnt, const float2* __restrict__ tw)
 {
     int l = logn - 1;
     while (l >= 0) {
-        if (l >= 2) { fft_dif_pass<3>(x, logn, cnt, l, tw); l -= 3; }
-        else if (l == 1) { fft_dif_pass<2>(x, logn, cnt, l, tw); l -= 2; }
-        else { fft_dif_pass<1>(x, logn, cnt, l, tw); l -= 1; }
+        if (l >= 2) { fft_dif_pass<3, NT>(x, logn, cnt, l, tw); l -= 3; }
+        else if (l == 1) { fft_dif_pass<2, NT>(x, logn, cnt, l, tw); l -= 2; }
+        else { fft_dif_pass<1, NT>(x, logn, cnt, l, tw); l -= 1; }
     }
 }
 
-template <int S>
+template <int S, int NT>
 __device__ __forceinline__ void fft_dit_pass(float2* x, int logn, int cnt, int l_lo, const float2* __restrict__ tw)
 {
     constexpr int M = 1 << S;
@@ -161,7 +199,7 @@ __device__ __forceinline__ void fft_dit_pass(float2* x, int logn, int cnt, int l
     const int n = 1 << logn;
     const int gps = n >> S;
     const int groups = cnt * gps;
-    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+    for (int g = threadIdx.x; g < groups; g += NT) {
         const int seq = g / gps, gi = g - seq * gps;
         const int low = gi & ((1 << l_lo) - 1), high = gi >> l_lo;
         const int i0 = (high << (l_hi + 1)) + low;
@@ -192,14 +230,15 @@ __device__ __forceinline__ void fft_dit_pass(float2* x, int logn, int cnt, int l
 }
 
 // backward (sign +1), decimation in time: bit-reversed order in, natural order out, unnormalised
+template <int NT>
 __device__ void fft_dit_inv(float2* x, int logn, int cnt, const float2* __restrict__ tw)
 {
     int l = 0;
     while (l < logn) {
         const int left = logn - l;
-        if (left >= 3) { fft_dit_pass<3>(x, logn, cnt, l, tw); l += 3; }
-        else if (left == 2) { fft_dit_pass<2>(x, logn, cnt, l, tw); l += 2; }
-        else { fft_dit_pass<1>(x, logn, cnt, l, tw); l += 1; }
+        if (left >= 3) { fft_dit_pass<3, NT>(x, logn, cnt, l, tw); l += 3; }
+        else if (left == 2) { fft_dit_pass<2, NT>(x, logn, cnt, l, tw); l += 2; }
+        else { fft_dit_pass<1, NT>(x, logn, cnt, l, tw); l += 1; }
     }
 }
 
@@ -216,6 +255,35 @@ __device__ __forceinline__ float load_px(const void* img, int dtype, size_t stri
     return ((const float*)row)[x];
 }
 
+// Pixels of a tile's rows -> LDS as complex values, U loads in flight per thread: coordinates are
+// clamped into the raster so that every load is legal and unconditional, pixels outside the bbox or
+// the raster are replaced by 0 afterwards.  w = 2^logw.
+template <typename T, int NT, int U>
+__device__ __forceinline__ void stage_pixels(float2* x, const void* img, const XcImage& im, const mis_rect bb,
+                                             int row0, int w, int logw, int n)
+{
+    for (int base = 0; base < n; base += NT * U) {
+        float f[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + (int)threadIdx.x + NT * u;
+            const int ry = row0 + (i >> logw), rx = i & (w - 1);
+            const int sx = bb.minx + rx, sy = bb.miny + ry;
+            ok[u] = rx < bb.width && ry < bb.height && sx >= 0 && sx < im.iw && sy >= 0 && sy < im.ih;
+            const int cx = min(max(sx, 0), im.iw - 1), cy = min(max(sy, 0), im.ih - 1);
+            f[u] = (float)((const T*)((const unsigned char*)img + (size_t)cy * im.stride))[cx];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) asm volatile("" : "+v"(f[u]));
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + (int)threadIdx.x + NT * u;
+            if (i < n) x[i] = make_float2(ok[u] ? f[u] : 0.f, 0.f);
+        }
+    }
+}
+
 // stage 1: grid (rows/RB, 2 images, tiles).  RB rows of one tile per workgroup.
 // spec layout: [tile][img][h][w] float2
 __global__ __launch_bounds__(256) void xc_rows_fwd(XcImage im, const mis_rect* __restrict__ r1,
@@ -228,22 +296,16 @@ __global__ __launch_bounds__(256) void xc_rows_fwd(XcImage im, const mis_rect* _
     const int t = blockIdx.z, side = blockIdx.y, row0 = blockIdx.x * RB;
     const mis_rect bb = side ? r2[tile0 + t] : r1[tile0 + t];
     const void* img = im.img[side];
-    for (int i = threadIdx.x; i < RB * w; i += blockDim.x) {
-        const int ry = row0 + i / w, rx = i % w;
-        float v = 0.f;
-        // image3.cpp:322-328: the buffer is zeroed, then the bbox region is read into it
-        if (rx < bb.width && ry < bb.height) {
-            const int sx = bb.minx + rx, sy = bb.miny + ry;
-            if (sx >= 0 && sx < im.iw && sy >= 0 && sy < im.ih) v = load_px(img, im.dtype, im.stride, sx, sy);
-        }
-        x[i] = make_float2(v, 0.f);
-    }
+    // image3.cpp:322-328: the buffer is zeroed, then the bbox region is read into it
+    if (im.dtype == MIS_U8) stage_pixels<uint8_t, 256, 8>(x, img, im, bb, row0, w, logw, RB * w);
+    else if (im.dtype == MIS_U16) stage_pixels<uint16_t, 256, 8>(x, img, im, bb, row0, w, logw, RB * w);
+    else stage_pixels<float, 256, 8>(x, img, im, bb, row0, w, logw, RB * w);
     float2* stw = x + (size_t)RB * w;               // twiddles in LDS: every butterfly reads one
-    for (int i = threadIdx.x; i < w / 2; i += blockDim.x) stw[i] = tw[i];
+    stage_contiguous<256, 2>(stw, tw, w / 2);
     __syncthreads();
-    fft_dif_fwd(x, logw, RB, stw);
+    fft_dif_fwd<256>(x, logw, RB, stw);
     float2* out = spec + ((size_t)(t * 2 + side) * h + row0) * w;
-    for (int i = threadIdx.x; i < RB * w; i += blockDim.x) out[i] = x[i];
+    for (int i = threadIdx.x; i < RB * w; i += 256) out[i] = x[i];
 }
 
 // stage 2: grid (w/CB, tiles).  CB adjacent columns of both spectra of one tile per workgroup.
@@ -257,24 +319,48 @@ __global__ __launch_bounds__(512) void xc_cols(int w, int h, int logh, int CB, f
     const int t = blockIdx.y, c0 = blockIdx.x * CB;
     float2* sa = spec + (size_t)(t * 2) * h * w;
     float2* sb = sa + (size_t)h * w;
-    for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
-        const int r = i / CB, c = i % CB;
-        A[c * h + r] = sa[(size_t)r * w + c0 + c];
-        B[c * h + r] = sb[(size_t)r * w + c0 + c];
+    if (CB >= 2) {
+        // 16-byte loads (two adjacent columns of a row), four per spectrum in flight per thread
+        const int hc = CB >> 1, lhc = __ffs(hc) - 1, n4 = hc * h;
+        for (int base = 0; base < n4; base += 512 * 4) {
+            float4 va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = min(base + (int)threadIdx.x + 512 * u, n4 - 1);
+                const size_t o = (size_t)(i >> lhc) * w + c0 + 2 * (i & (hc - 1));
+                va[u] = *(const float4*)(sa + o);
+                vb[u] = *(const float4*)(sb + o);
+            }
+            pin_loaded(va); pin_loaded(vb);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + (int)threadIdx.x + 512 * u;
+                if (i < n4) {
+                    const int r = i >> lhc, c = 2 * (i & (hc - 1));
+                    A[c * h + r] = make_float2(va[u].x, va[u].y); A[(c + 1) * h + r] = make_float2(va[u].z, va[u].w);
+                    B[c * h + r] = make_float2(vb[u].x, vb[u].y); B[(c + 1) * h + r] = make_float2(vb[u].z, vb[u].w);
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < h; i += 512) {
+            A[i] = sa[(size_t)i * w + c0];
+            B[i] = sb[(size_t)i * w + c0];
+        }
     }
     float2* stw = B + (size_t)CB * h;
-    for (int i = threadIdx.x; i < h / 2; i += blockDim.x) stw[i] = tw[i];
+    stage_contiguous<512, 1>(stw, tw, h / 2);
     __syncthreads();
-    fft_dif_fwd(A, logh, 2 * CB, stw);       // A and B are adjacent: 2*CB sequences
+    fft_dif_fwd<512>(A, logh, 2 * CB, stw);       // A and B are adjacent: 2*CB sequences
     // runFFT divides each spectrum by sqrt(N) (image3.cpp:331-334); product image3.cpp:392-394
-    for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
+    for (int i = threadIdx.x; i < CB * h; i += 512) {
         float2 a = A[i], b = B[i];
         a.x *= scale; a.y *= scale; b.x *= scale; b.y *= scale;
         A[i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
     }
     __syncthreads();
-    fft_dit_inv(A, logh, CB, stw);
-    for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
+    fft_dit_inv<512>(A, logh, CB, stw);
+    for (int i = threadIdx.x; i < CB * h; i += 512) {
         const int r = i / CB, c = i % CB;
         sa[(size_t)r * w + c0 + c] = A[c * h + r];
     }
@@ -291,6 +377,21 @@ __device__ __forceinline__ float wave_max_f(float v)
     return v;
 }
 
+// The argmax key of a tile is combined with atomics on one address.  A workgroup combines its
+// wavefronts through LDS first and issues the atomic only when a plain load says it would change
+// the value (keys only grow, so a stale load merely costs a redundant atomic).
+__device__ __forceinline__ void tile_commit_key(unsigned long long* keys, int t, unsigned long long best)   // wave-reduced
+{
+    __shared__ unsigned long long s_k[16];
+    const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) s_k[wv] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; i++) best = s_k[i] > best ? s_k[i] : best;
+        if (best > *(volatile unsigned long long*)&keys[t]) atomicMax(&keys[t], best);
+    }
+}
+
 // stage 3: grid (rows/RB, tiles).  Inverse row transform, divide by sqrt(N) (image3.cpp:401-405),
 // magnitude, tile minimum and maximum (image3.cpp:402-411).  minmax[tile] = {min bits, max bits}
 // of non-negative floats, whose unsigned bit patterns order like the values.
@@ -303,14 +404,14 @@ __global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, i
     float2* x = (float2*)smem_raw;
     const int t = blockIdx.y, row0 = blockIdx.x * RB;
     const float2* in = spec + ((size_t)(t * 2) * h + row0) * w;
-    for (int i = threadIdx.x; i < RB * w; i += blockDim.x) x[i] = in[i];
+    stage_contiguous<256, 4>(x, in, RB * w);
     float2* stw = x + (size_t)RB * w;
-    for (int i = threadIdx.x; i < w / 2; i += blockDim.x) stw[i] = tw[i];
+    stage_contiguous<256, 2>(stw, tw, w / 2);
     __syncthreads();
-    fft_dit_inv(x, logw, RB, stw);
+    fft_dit_inv<256>(x, logw, RB, stw);
     float* out = surf + ((size_t)t * h + row0) * w;
     float lo = INFINITY, hi = 0.f;
-    for (int i = threadIdx.x; i < RB * w; i += blockDim.x) {
+    for (int i = threadIdx.x; i < RB * w; i += 256) {
         const float2 v = x[i];
         // cabs() of the complex float promoted to double (image3.cpp:407-410)
         const float m = (float)hypot((double)(v.x * scale), (double)(v.y * scale));
@@ -318,7 +419,7 @@ __global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, i
         lo = fminf(lo, m); hi = fmaxf(hi, m);
     }
     lo = wave_min_f(lo); hi = wave_max_f(hi);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
         atomicMin(&minmax[2 * t], __float_as_uint(lo));
         atomicMax(&minmax[2 * t + 1], __float_as_uint(hi));
     }
@@ -352,8 +453,8 @@ __global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsig
     const float range = mx - mn;
     float* srow = surf + ((size_t)t * h + y) * w;
     const int w2 = (w / 2) * 2, h2 = (h / 2) * 2;
-    for (int i = threadIdx.x; i < XC_GAUSS_K; i += blockDim.x) g[i] = gauss[i];
-    for (int x = threadIdx.x; x < w; x += blockDim.x) {
+    for (int i = threadIdx.x; i < XC_GAUSS_K; i += 256) g[i] = gauss[i];
+    for (int x = threadIdx.x; x < w; x += 256) {
         const float m = srow[x];
         // pre: the surface already holds the product of the normalised band surfaces
         const float o = pre ? m : (float)(((double)m - (double)mn) / (double)range);
@@ -362,7 +463,7 @@ __global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsig
     }
     __syncthreads();
     const int kw = (w == 1) ? 1 : XC_GAUSS_K, rx = kw / 2;
-    for (int i = threadIdx.x; i < ((w + 163) & ~3); i += blockDim.x) {
+    for (int i = threadIdx.x; i < ((w + 163) & ~3); i += 256) {
         float v = 0.f;
         if (i < w + kw - 1) {
             const int sx = reflect101(i - rx, w);
@@ -373,13 +474,13 @@ __global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsig
     __syncthreads();
     float* trow = tmp + ((size_t)t * h + y) * w;
     if (kw == 1) {
-        for (int x = threadIdx.x; x < w; x += blockDim.x) trow[x] = prow[x];
+        for (int x = threadIdx.x; x < w; x += 256) trow[x] = prow[x];
         return;
     }
     // four adjacent outputs per thread: the taps slide through registers, so every padded sample and
     // every coefficient is read from LDS once per four outputs (16-byte reads); each output still
     // accumulates its taps left to right with separate multiply and add
-    for (int x0 = 4 * threadIdx.x; x0 < w; x0 += 4 * blockDim.x) {
+    for (int x0 = 4 * threadIdx.x; x0 < w; x0 += 4 * 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         float4 v = *(const float4*)(prow + x0);
 #pragma unroll 2
@@ -431,18 +532,39 @@ __global__ __launch_bounds__(256) void xc_colblur_argmax(int w, int h, const flo
                                                          float* __restrict__ dog_out,
                                                          unsigned long long* __restrict__ keys)
 {
-    __shared__ float col[(XC_RB5 + 2 * XC_GAUSS_R) * 64];
+    __shared__ __attribute__((aligned(16))) float col[(((XC_RB5 + 2 * XC_GAUSS_R) * 16 + 255) / 256) * 1024];
     __shared__ float g[XC_GAUSS_K];
     const int t = blockIdx.z, x0 = blockIdx.x * 64, y0 = blockIdx.y * XC_RB5;
     const int kh = (h == 1) ? 1 : XC_GAUSS_K, ry = kh / 2;
     const int w2 = (w / 2) * 2, h2 = (h / 2) * 2;
     const float* tt = tmp + (size_t)t * h * w;
-    for (int i = threadIdx.x; i < XC_GAUSS_K; i += blockDim.x) g[i] = gauss[i];
+    for (int i = threadIdx.x; i < XC_GAUSS_K; i += 256) g[i] = gauss[i];
     const int nrows = XC_RB5 + 2 * ry;
-    for (int i = threadIdx.x; i < nrows * 64; i += blockDim.x) {
-        const int r = i >> 6, c = i & 63;
-        const int sy = reflect101(y0 - ry + r, h);
-        col[i] = (x0 + c < w) ? tt[(size_t)sy * w + x0 + c] : 0.f;
+    if ((w & 3) == 0 && x0 + 64 <= w && h >= 256) {
+        // 16-byte loads, all of a thread's requests in flight before the first is stored.  The row
+        // index is reflected without a loop (one reflection suffices for h >= 256) and clamped rather
+        // than tested: any branch between two loads makes the compiler wait for the first one, and
+        // the staging then is a chain of memory round trips several times longer than the arithmetic.
+        constexpr int NV = ((XC_RB5 + 2 * XC_GAUSS_R) * 16 + 255) / 256;
+        float4 v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; q++) {
+            const int i = threadIdx.x + 256 * q, r = min(i >> 4, nrows - 1), c4 = i & 15;
+            int sy = y0 - ry + r;
+            sy = sy < 0 ? -sy : sy;
+            sy = sy >= h ? 2 * h - 2 - sy : sy;
+            v[q] = *(const float4*)(tt + (size_t)sy * w + x0 + 4 * c4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NV; q++)                 // unconditional (col is padded to NV * 256 float4): a test here pulls the load back in
+            *(float4*)(col + 4 * (threadIdx.x + 256 * q)) = v[q];
+    } else {
+        for (int i = threadIdx.x; i < nrows * 64; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            const int sy = reflect101(y0 - ry + r, h);
+            col[i] = (x0 + c < w) ? tt[(size_t)sy * w + x0 + c] : 0.f;
+        }
     }
     __syncthreads();
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -497,7 +619,7 @@ __global__ __launch_bounds__(256) void xc_colblur_argmax(int w, int h, const flo
         unsigned long long other = __shfl_xor(best, o);
         best = other > best ? other : best;
     }
-    if ((threadIdx.x & 63) == 0 && best) atomicMax(&keys[t], best);
+    tile_commit_key(keys, t, best);
 }
 
 // stage 6: one thread per tile (image3.cpp:507-516)
@@ -550,7 +672,8 @@ struct XgDft { int n, M, logM, pow2; const float2* chirp; const float2* filt; co
 
 // In-place DFT of sequences of length d.n.  Sequence r lives at data + (r / per_batch) * batch_stride
 // + (r % per_batch) * n.  inverse != 0: unnormalised backward transform (conjugate, forward, conjugate).
-__global__ __launch_bounds__(512) void xg_dft_rows(float2* __restrict__ data, XgDft d, int per_batch,
+template <int NT>
+__global__ __launch_bounds__(NT) void xg_dft_rows(float2* __restrict__ data, XgDft d, int per_batch,
                                                    size_t batch_stride, int inverse)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -559,27 +682,27 @@ __global__ __launch_bounds__(512) void xg_dft_rows(float2* __restrict__ data, Xg
     float2* row = data + (size_t)(r / per_batch) * batch_stride + (size_t)(r % per_batch) * d.n;
     const float sgn = inverse ? -1.f : 1.f;
     if (d.pow2) {
-        for (int i = threadIdx.x; i < d.n; i += blockDim.x) { float2 v = row[i]; v.y *= sgn; x[i] = v; }
+        for (int i = threadIdx.x; i < d.n; i += NT) { float2 v = row[i]; v.y *= sgn; x[i] = v; }
         __syncthreads();
-        fft_dif_fwd(x, d.logM, 1, d.tw);
-        for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+        fft_dif_fwd<NT>(x, d.logM, 1, d.tw);
+        for (int i = threadIdx.x; i < d.n; i += NT) {
             float2 v = x[i]; v.y *= sgn;
             row[d.logM ? bitrev(i, d.logM) : 0] = v;
         }
         return;
     }
-    for (int i = threadIdx.x; i < d.M; i += blockDim.x) {
+    for (int i = threadIdx.x; i < d.M; i += NT) {
         float2 v = make_float2(0.f, 0.f);
         if (i < d.n) { v = row[i]; v.y *= sgn; v = cmul(v, d.chirp[i]); }
         x[i] = v;
     }
     __syncthreads();
-    fft_dif_fwd(x, d.logM, 1, d.tw);
-    for (int i = threadIdx.x; i < d.M; i += blockDim.x) x[i] = cmul(x[i], d.filt[i]);
+    fft_dif_fwd<NT>(x, d.logM, 1, d.tw);
+    for (int i = threadIdx.x; i < d.M; i += NT) x[i] = cmul(x[i], d.filt[i]);
     __syncthreads();
-    fft_dit_inv(x, d.logM, 1, d.tw);
+    fft_dit_inv<NT>(x, d.logM, 1, d.tw);
     const float inv_m = 1.0f / (float)d.M;
-    for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+    for (int i = threadIdx.x; i < d.n; i += NT) {
         float2 v = cmul(x[i], d.chirp[i]);
         row[i] = make_float2(v.x * inv_m, sgn * v.y * inv_m);
     }
@@ -785,9 +908,11 @@ static int launch_dft(mis_ctx* ctx, float2* data, const XgDft& d, int nseq, int 
 {
     const size_t sh = (size_t)d.M * sizeof(float2);
     if (sh > 64 * 1024)
-        MIS_HIP(ctx, hipFuncSetAttribute((const void*)xg_dft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL(xg_dft_rows, dim3((unsigned)nseq), dim3(d.M >= 2048 ? 512 : 256), sh, ctx->stream,
-                       data, d, per_batch, batch_stride, inverse);
+        MIS_HIP(ctx, hipFuncSetAttribute((const void*)xg_dft_rows<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    if (d.M >= 2048)
+        hipLaunchKernelGGL(xg_dft_rows<512>, dim3((unsigned)nseq), dim3(512), sh, ctx->stream, data, d, per_batch, batch_stride, inverse);
+    else
+        hipLaunchKernelGGL(xg_dft_rows<256>, dim3((unsigned)nseq), dim3(256), sh, ctx->stream, data, d, per_batch, batch_stride, inverse);
     return MIS_OK;
 }
 
@@ -979,12 +1104,12 @@ __global__ __launch_bounds__(256) void xc_fft_rows_only(const void* __restrict__
     const int t = blockIdx.y, row0 = blockIdx.x * RB;
     const int bpp = dtype == MIS_U8 ? 1 : dtype == MIS_U16 ? 2 : 4;
     const unsigned char* base = (const unsigned char*)in + (size_t)t * h * w * bpp;
-    for (int i = threadIdx.x; i < RB * w; i += blockDim.x)
+    for (int i = threadIdx.x; i < RB * w; i += 256)
         x[i] = make_float2(load_px(base, dtype, (size_t)w * bpp, i % w, row0 + i / w), 0.f);
     __syncthreads();
-    fft_dif_fwd(x, logw, RB, tw);
+    fft_dif_fwd<256>(x, logw, RB, tw);
     float2* o = out + ((size_t)t * h + row0) * w;
-    for (int i = threadIdx.x; i < RB * w; i += blockDim.x) o[i] = x[i];     // columns bit-reversed
+    for (int i = threadIdx.x; i < RB * w; i += 256) o[i] = x[i];     // columns bit-reversed
 }
 
 __global__ __launch_bounds__(512) void xc_fft_cols_only(int w, int h, int logw, int logh, int CB, double norm,
@@ -996,14 +1121,14 @@ __global__ __launch_bounds__(512) void xc_fft_cols_only(int w, int h, int logw, 
     const int t = blockIdx.y, c0 = blockIdx.x * CB;
     const float2* src = in + (size_t)t * h * w;
     float2* dst = out + (size_t)t * h * w;
-    for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
+    for (int i = threadIdx.x; i < CB * h; i += 512) {
         const int r = i / CB, c = i % CB;
         A[c * h + r] = src[(size_t)r * w + c0 + c];
     }
     __syncthreads();
-    fft_dif_fwd(A, logh, CB, tw);
+    fft_dif_fwd<512>(A, logh, CB, tw);
     // undo both bit reversals on the way out; divide by sqrt(N) held in double (image-fft.cpp:84-87)
-    for (int i = threadIdx.x; i < CB * h; i += blockDim.x) {
+    for (int i = threadIdx.x; i < CB * h; i += 512) {
         const int r = i / CB, c = i % CB;
         const float2 v = A[c * h + r];
         const int rr = bitrev(r, logh), cc = bitrev(c0 + c, logw);
