@@ -122,19 +122,28 @@ __global__ __launch_bounds__(256) void ncc_tables_kernel(const T* __restrict__ i
     const bool colok = (x >= r && x < W - r);
     int s1 = 0, s2 = 0;                 // vertical sums of the ring: rows yy-2r .. yy
     int slot = 0;
-    // a row is fetched into registers one iteration ahead and published to LDS after the arithmetic
-    auto fetch = [&](int yy, int i) -> int {
-        const int xs = x0 - r + i;
-        return (yy >= 0 && yy < H && xs >= 0 && xs < W && i < 256 + 2 * r) ? (int)img[(size_t)yy * stride_px + xs] - 128 : 0;
+    // A row is fetched into registers one iteration ahead and published to LDS after the arithmetic.
+    // Every load of an iteration is issued unconditionally at its top (coordinates clamped into the
+    // raster, the value replaced afterwards where the pixel does not exist): a load inside a
+    // conditional block is waited for at the end of that block, which turns the walk down the band
+    // into one exposed memory round trip per row.
+    const int Wm = W - 1, Hm = H - 1;
+    auto raw = [&](int yy, int xs) -> int {
+        return (int)img[(size_t)min(max(yy, 0), Hm) * stride_px + min(max(xs, 0), Wm)] - 128;
     };
-    rowbuf[0][tid] = fetch(y0 - r, tid);
-    if (tid < 32) rowbuf[0][256 + tid] = fetch(y0 - r, 256 + tid);
+    auto inside = [&](int yy, int xs) -> bool { return yy >= 0 && yy < H && xs >= 0 && xs < W; };
+    const int xa = x0 - r + tid, xb = x0 - r + 256 + (tid & 31);   // staged columns of this thread (xb: halo, threads 0..31)
+    {
+        const int v0 = raw(y0 - r, xa), v1 = raw(y0 - r, xb);
+        rowbuf[0][tid] = inside(y0 - r, xa) ? v0 : 0;
+        if (tid < 32) rowbuf[0][256 + tid] = (inside(y0 - r, xb) && tid < 2 * r) ? v1 : 0;
+    }
     __syncthreads();
     for (int yy = y0 - r; yy < y1 + r; yy++) {
         const int buf = (yy - (y0 - r)) & 1;
         const bool more = (yy + 1 < y1 + r);
-        int nxt0 = 0, nxt1 = 0;
-        if (more) { nxt0 = fetch(yy + 1, tid); if (tid < 32) nxt1 = fetch(yy + 1, 256 + tid); }
+        int nxt0 = raw(yy + 1, xa), nxt1 = raw(yy + 1, xb);
+        int pa = raw(yy - r, x), pb = raw(yy - r - Wn, x);          // own pixel and the one Wn rows above, for the packed pair
         int h1 = 0, h2 = 0;
         for (int i = 0; i <= 2 * r; i++) { const int v = rowbuf[buf][tid + i]; h1 += v; h2 += v * v; }
         if (yy - (y0 - r) >= Wn) {      // the ring is full: drop the row that leaves the window
@@ -146,15 +155,15 @@ __global__ __launch_bounds__(256) void ncc_tables_kernel(const T* __restrict__ i
         slot = (slot + 1 == Wn) ? 0 : slot + 1;
         s1 += h1; s2 += h2;
 
+        asm volatile("" : "+v"(nxt0), "+v"(nxt1), "+v"(pa), "+v"(pb));     // the loads stay above the arithmetic
+        nxt0 = inside(yy + 1, xa) ? nxt0 : 0;
+        nxt1 = (inside(yy + 1, xb) && tid < 2 * r) ? nxt1 : 0;
         const int y = yy - r;           // the window centred at y is complete now
         if (y >= y0 && x < pitch) {
             const size_t o = (size_t)y * pitch + x;
             // packed pair: this row and the row Wn above
-            float a = 0.f, b = 0.f;
-            if (x < W) {
-                a = (float)((int)img[(size_t)y * stride_px + x] - 128);
-                if (y - Wn >= 0) b = (float)((int)img[(size_t)(y - Wn) * stride_px + x] - 128);
-            }
+            const float a = (x < W) ? (float)pa : 0.f;
+            const float b = (x < W && y - Wn >= 0) ? (float)pb : 0.f;
             half2_t h;
             h.x = (_Float16)a;
             h.y = (_Float16)(LEFT ? -b : b);
