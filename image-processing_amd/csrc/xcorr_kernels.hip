@@ -377,9 +377,27 @@ __device__ __forceinline__ float wave_max_f(float v)
     return v;
 }
 
-// The argmax key of a tile is combined with atomics on one address.  A workgroup combines its
-// wavefronts through LDS first and issues the atomic only when a plain load says it would change
-// the value (keys only grow, so a stale load merely costs a redundant atomic).
+// Per-tile extrema and argmax keys are combined with atomics on one address per tile.  Same-address
+// atomics are serialised in the memory system (of the order of 10 ns each) and the workgroups of a
+// tile run at the same time, so a tile's atomics form a chain: with one atomic per wavefront that
+// chain was 60 % of the inverse row kernel's time.  The wavefronts of a workgroup are therefore
+// combined through LDS first.  (Testing the current value with a plain load before the atomic
+// costs more than it saves: that load is a full memory round trip in front of every atomic.)
+// tile extrema: the workgroup's wavefronts are combined through LDS, then one atomic pair
+__device__ __forceinline__ void tile_commit_minmax(unsigned* minmax, int t, float lo, float hi)   // wave-reduced lo, hi
+{
+    __shared__ float s_lo[16], s_hi[16];
+    const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; i++) { lo = fminf(lo, s_lo[i]); hi = fmaxf(hi, s_hi[i]); }
+        if (lo <= hi) {
+            atomicMin(&minmax[2 * t], __float_as_uint(lo));
+            atomicMax(&minmax[2 * t + 1], __float_as_uint(hi));
+        }
+    }
+}
 __device__ __forceinline__ void tile_commit_key(unsigned long long* keys, int t, unsigned long long best)   // wave-reduced
 {
     __shared__ unsigned long long s_k[16];
@@ -388,7 +406,7 @@ __device__ __forceinline__ void tile_commit_key(unsigned long long* keys, int t,
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 1; i < nw; i++) best = s_k[i] > best ? s_k[i] : best;
-        if (best > *(volatile unsigned long long*)&keys[t]) atomicMax(&keys[t], best);
+        if (best) atomicMax(&keys[t], best);
     }
 }
 
@@ -419,10 +437,7 @@ __global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, i
         lo = fminf(lo, m); hi = fmaxf(hi, m);
     }
     lo = wave_min_f(lo); hi = wave_max_f(hi);
-    if ((threadIdx.x & 63) == 0 && lo <= hi) {
-        atomicMin(&minmax[2 * t], __float_as_uint(lo));
-        atomicMax(&minmax[2 * t + 1], __float_as_uint(hi));
-    }
+    tile_commit_minmax(minmax, t, lo, hi);
 }
 
 // OpenCV borderInterpolate(p, len, BORDER_REFLECT_101)
@@ -766,10 +781,7 @@ __global__ __launch_bounds__(256) void xg_abs_minmax(const float2* __restrict__ 
         lo = hi = m;
     }
     lo = wave_min_f(lo); hi = wave_max_f(hi);
-    if ((threadIdx.x & 63) == 0 && lo <= hi) {
-        atomicMin(&minmax[2 * t], __float_as_uint(lo));
-        atomicMax(&minmax[2 * t + 1], __float_as_uint(hi));
-    }
+    tile_commit_minmax(minmax, t, lo, hi);
 }
 
 // raster of any pixel type -> complex (image-fft.cpp:66-71)
