@@ -105,6 +105,13 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// LDS index swizzle of the padded layouts: one unused element after every eight.  The later passes
+// address LDS with lane strides of 8 or 64 elements (64 or 512 bytes), which map whole groups of
+// lanes onto the same banks; with the pad the strides become 9 and 72 elements and a wavefront's
+// accesses spread over all banks.  Arrays hold n + n/8 elements (n a multiple of 8).
+template <bool PAD>
+__device__ __forceinline__ int xp(int i) { return PAD ? i + (i >> 3) : i; }
+
 // Keeps every element of v[] behind this point: loads issued above cannot be moved (back) into the
 // conditional blocks below, where the compiler would wait for each one separately.
 template <int U>
@@ -116,7 +123,7 @@ __device__ __forceinline__ void pin_loaded(float4 (&v)[U])
 
 // Contiguous global -> LDS copy of n float2 (n even, 16-byte aligned on both sides) by an NT-thread
 // workgroup: 16-byte loads, U of them in flight per thread (clamped addresses, tested stores).
-template <int NT, int U>
+template <int NT, int U, bool PAD = false>
 __device__ __forceinline__ void stage_contiguous(float2* dst, const float2* __restrict__ src, int n)
 {
     if (n & 1) {                                     // degenerate sizes only
@@ -134,7 +141,12 @@ __device__ __forceinline__ void stage_contiguous(float2* dst, const float2* __re
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = base + (int)threadIdx.x + NT * u;
-            if (i < n4) d4[i] = v[u];
+            if (i < n4) {
+                if (PAD) {                           // the pad breaks the 16-byte alignment of every second pair
+                    dst[xp<PAD>(2 * i)] = make_float2(v[u].x, v[u].y);
+                    dst[xp<PAD>(2 * i + 1)] = make_float2(v[u].z, v[u].w);
+                } else d4[i] = v[u];
+            }
         }
     }
 }
@@ -143,7 +155,7 @@ __device__ __forceinline__ void stage_contiguous(float2* dst, const float2* __re
 // elements they connect (indices base + m * 2^l_lo, m = 0 .. 2^S - 1): the arithmetic is exactly
 // that of S radix-2 passes, with a third of the LDS traffic and barriers.
 // Stage with half = 2^l: butterfly (i, i + half), twiddle index (i mod half) << (logn - 1 - l).
-template <int S, int NT>
+template <int S, int NT, bool PAD>
 __device__ __forceinline__ void fft_dif_pass(float2* x, int logn, int cnt, int l_hi, const float2* __restrict__ tw)
 {
     constexpr int M = 1 << S;
@@ -155,10 +167,10 @@ __device__ __forceinline__ void fft_dif_pass(float2* x, int logn, int cnt, int l
         const int seq = g / gps, gi = g - seq * gps;
         const int low = gi & ((1 << l_lo) - 1), high = gi >> l_lo;
         const int i0 = (high << (l_hi + 1)) + low;            // index of element m = 0 inside the sequence
-        float2* px = x + (size_t)seq * n + i0;
+        const int b0 = seq * n + i0;
         float2 v[M];
 #pragma unroll
-        for (int m = 0; m < M; m++) v[m] = px[m << l_lo];
+        for (int m = 0; m < M; m++) v[m] = x[xp<PAD>(b0 + (m << l_lo))];
 #pragma unroll
         for (int st = 0; st < S; st++) {
             const int l = l_hi - st;
@@ -174,24 +186,24 @@ __device__ __forceinline__ void fft_dif_pass(float2* x, int logn, int cnt, int l
             }
         }
 #pragma unroll
-        for (int m = 0; m < M; m++) px[m << l_lo] = v[m];
+        for (int m = 0; m < M; m++) x[xp<PAD>(b0 + (m << l_lo))] = v[m];
     }
     __syncthreads();
 }
 
 // forward (sign -1), decimation in frequency: natural order in, bit-reversed order out
-template <int NT>
+template <int NT, bool PAD = false>
 __device__ void fft_dif_fwd(float2* x, int logn, int cnt, const float2* __restrict__ tw)
 {
     int l = logn - 1;
     while (l >= 0) {
-        if (l >= 2) { fft_dif_pass<3, NT>(x, logn, cnt, l, tw); l -= 3; }
-        else if (l == 1) { fft_dif_pass<2, NT>(x, logn, cnt, l, tw); l -= 2; }
-        else { fft_dif_pass<1, NT>(x, logn, cnt, l, tw); l -= 1; }
+        if (l >= 2) { fft_dif_pass<3, NT, PAD>(x, logn, cnt, l, tw); l -= 3; }
+        else if (l == 1) { fft_dif_pass<2, NT, PAD>(x, logn, cnt, l, tw); l -= 2; }
+        else { fft_dif_pass<1, NT, PAD>(x, logn, cnt, l, tw); l -= 1; }
     }
 }
 
-template <int S, int NT>
+template <int S, int NT, bool PAD>
 __device__ __forceinline__ void fft_dit_pass(float2* x, int logn, int cnt, int l_lo, const float2* __restrict__ tw)
 {
     constexpr int M = 1 << S;
@@ -203,10 +215,10 @@ __device__ __forceinline__ void fft_dit_pass(float2* x, int logn, int cnt, int l
         const int seq = g / gps, gi = g - seq * gps;
         const int low = gi & ((1 << l_lo) - 1), high = gi >> l_lo;
         const int i0 = (high << (l_hi + 1)) + low;
-        float2* px = x + (size_t)seq * n + i0;
+        const int b0 = seq * n + i0;
         float2 v[M];
 #pragma unroll
-        for (int m = 0; m < M; m++) v[m] = px[m << l_lo];
+        for (int m = 0; m < M; m++) v[m] = x[xp<PAD>(b0 + (m << l_lo))];
 #pragma unroll
         for (int st = 0; st < S; st++) {
             const int l = l_lo + st;
@@ -224,21 +236,21 @@ __device__ __forceinline__ void fft_dit_pass(float2* x, int logn, int cnt, int l
             }
         }
 #pragma unroll
-        for (int m = 0; m < M; m++) px[m << l_lo] = v[m];
+        for (int m = 0; m < M; m++) x[xp<PAD>(b0 + (m << l_lo))] = v[m];
     }
     __syncthreads();
 }
 
 // backward (sign +1), decimation in time: bit-reversed order in, natural order out, unnormalised
-template <int NT>
+template <int NT, bool PAD = false>
 __device__ void fft_dit_inv(float2* x, int logn, int cnt, const float2* __restrict__ tw)
 {
     int l = 0;
     while (l < logn) {
         const int left = logn - l;
-        if (left >= 3) { fft_dit_pass<3, NT>(x, logn, cnt, l, tw); l += 3; }
-        else if (left == 2) { fft_dit_pass<2, NT>(x, logn, cnt, l, tw); l += 2; }
-        else { fft_dit_pass<1, NT>(x, logn, cnt, l, tw); l += 1; }
+        if (left >= 3) { fft_dit_pass<3, NT, PAD>(x, logn, cnt, l, tw); l += 3; }
+        else if (left == 2) { fft_dit_pass<2, NT, PAD>(x, logn, cnt, l, tw); l += 2; }
+        else { fft_dit_pass<1, NT, PAD>(x, logn, cnt, l, tw); l += 1; }
     }
 }
 
@@ -258,7 +270,7 @@ __device__ __forceinline__ float load_px(const void* img, int dtype, size_t stri
 // Pixels of a tile's rows -> LDS as complex values, U loads in flight per thread: coordinates are
 // clamped into the raster so that every load is legal and unconditional, pixels outside the bbox or
 // the raster are replaced by 0 afterwards.  w = 2^logw.
-template <typename T, int NT, int U>
+template <typename T, int NT, int U, bool PAD>
 __device__ __forceinline__ void stage_pixels(float2* x, const void* img, const XcImage& im, const mis_rect bb,
                                              int row0, int w, int logw, int n)
 {
@@ -279,13 +291,15 @@ __device__ __forceinline__ void stage_pixels(float2* x, const void* img, const X
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = base + (int)threadIdx.x + NT * u;
-            if (i < n) x[i] = make_float2(ok[u] ? f[u] : 0.f, 0.f);
+            if (i < n) x[xp<PAD>(i)] = make_float2(ok[u] ? f[u] : 0.f, 0.f);
         }
     }
 }
 
 // stage 1: grid (rows/RB, 2 images, tiles).  RB rows of one tile per workgroup.
 // spec layout: [tile][img][h][w] float2
+// PAD: padded LDS layout (xp), chosen by the host whenever the padded array fits.
+template <bool PAD>
 __global__ __launch_bounds__(256) void xc_rows_fwd(XcImage im, const mis_rect* __restrict__ r1,
                                                    const mis_rect* __restrict__ r2, int tile0,
                                                    int w, int h, int logw, int RB,
@@ -297,25 +311,26 @@ __global__ __launch_bounds__(256) void xc_rows_fwd(XcImage im, const mis_rect* _
     const mis_rect bb = side ? r2[tile0 + t] : r1[tile0 + t];
     const void* img = im.img[side];
     // image3.cpp:322-328: the buffer is zeroed, then the bbox region is read into it
-    if (im.dtype == MIS_U8) stage_pixels<uint8_t, 256, 8>(x, img, im, bb, row0, w, logw, RB * w);
-    else if (im.dtype == MIS_U16) stage_pixels<uint16_t, 256, 8>(x, img, im, bb, row0, w, logw, RB * w);
-    else stage_pixels<float, 256, 8>(x, img, im, bb, row0, w, logw, RB * w);
-    float2* stw = x + (size_t)RB * w;               // twiddles in LDS: every butterfly reads one
+    if (im.dtype == MIS_U8) stage_pixels<uint8_t, 256, 8, PAD>(x, img, im, bb, row0, w, logw, RB * w);
+    else if (im.dtype == MIS_U16) stage_pixels<uint16_t, 256, 8, PAD>(x, img, im, bb, row0, w, logw, RB * w);
+    else stage_pixels<float, 256, 8, PAD>(x, img, im, bb, row0, w, logw, RB * w);
+    float2* stw = x + (((size_t)xp<PAD>(RB * w) + 1) & ~(size_t)1);   // twiddles in LDS: every butterfly reads one
     stage_contiguous<256, 2>(stw, tw, w / 2);
     __syncthreads();
-    fft_dif_fwd<256>(x, logw, RB, stw);
+    fft_dif_fwd<256, PAD>(x, logw, RB, stw);
     float2* out = spec + ((size_t)(t * 2 + side) * h + row0) * w;
-    for (int i = threadIdx.x; i < RB * w; i += 256) out[i] = x[i];
+    for (int i = threadIdx.x; i < RB * w; i += 256) out[i] = x[xp<PAD>(i)];
 }
 
 // stage 2: grid (w/CB, tiles).  CB adjacent columns of both spectra of one tile per workgroup.
 // LDS: A[CB][h], B[CB][h] (column-major so that every column is one contiguous sequence).
+template <bool PAD>
 __global__ __launch_bounds__(512) void xc_cols(int w, int h, int logh, int CB, float scale,
                                                const float2* __restrict__ tw, float2* __restrict__ spec)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* A = (float2*)smem_raw;
-    float2* B = A + (size_t)CB * h;
+    const int nB = CB * h;                          // the second spectrum follows the first in one joint array
     const int t = blockIdx.y, c0 = blockIdx.x * CB;
     float2* sa = spec + (size_t)(t * 2) * h * w;
     float2* sb = sa + (size_t)h * w;
@@ -337,32 +352,32 @@ __global__ __launch_bounds__(512) void xc_cols(int w, int h, int logh, int CB, f
                 const int i = base + (int)threadIdx.x + 512 * u;
                 if (i < n4) {
                     const int r = i >> lhc, c = 2 * (i & (hc - 1));
-                    A[c * h + r] = make_float2(va[u].x, va[u].y); A[(c + 1) * h + r] = make_float2(va[u].z, va[u].w);
-                    B[c * h + r] = make_float2(vb[u].x, vb[u].y); B[(c + 1) * h + r] = make_float2(vb[u].z, vb[u].w);
+                    A[xp<PAD>(c * h + r)] = make_float2(va[u].x, va[u].y); A[xp<PAD>((c + 1) * h + r)] = make_float2(va[u].z, va[u].w);
+                    A[xp<PAD>(nB + c * h + r)] = make_float2(vb[u].x, vb[u].y); A[xp<PAD>(nB + (c + 1) * h + r)] = make_float2(vb[u].z, vb[u].w);
                 }
             }
         }
     } else {
         for (int i = threadIdx.x; i < h; i += 512) {
-            A[i] = sa[(size_t)i * w + c0];
-            B[i] = sb[(size_t)i * w + c0];
+            A[xp<PAD>(i)] = sa[(size_t)i * w + c0];
+            A[xp<PAD>(nB + i)] = sb[(size_t)i * w + c0];
         }
     }
-    float2* stw = B + (size_t)CB * h;
+    float2* stw = A + (((size_t)xp<PAD>(2 * nB) + 1) & ~(size_t)1);
     stage_contiguous<512, 1>(stw, tw, h / 2);
     __syncthreads();
-    fft_dif_fwd<512>(A, logh, 2 * CB, stw);       // A and B are adjacent: 2*CB sequences
+    fft_dif_fwd<512, PAD>(A, logh, 2 * CB, stw);       // A and B are adjacent: 2*CB sequences
     // runFFT divides each spectrum by sqrt(N) (image3.cpp:331-334); product image3.cpp:392-394
     for (int i = threadIdx.x; i < CB * h; i += 512) {
-        float2 a = A[i], b = B[i];
+        float2 a = A[xp<PAD>(i)], b = A[xp<PAD>(nB + i)];
         a.x *= scale; a.y *= scale; b.x *= scale; b.y *= scale;
-        A[i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+        A[xp<PAD>(i)] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
     }
     __syncthreads();
-    fft_dit_inv<512>(A, logh, CB, stw);
+    fft_dit_inv<512, PAD>(A, logh, CB, stw);
     for (int i = threadIdx.x; i < CB * h; i += 512) {
         const int r = i / CB, c = i % CB;
-        sa[(size_t)r * w + c0 + c] = A[c * h + r];
+        sa[(size_t)r * w + c0 + c] = A[xp<PAD>(c * h + r)];
     }
 }
 
@@ -413,6 +428,7 @@ __device__ __forceinline__ void tile_commit_key(unsigned long long* keys, int t,
 // stage 3: grid (rows/RB, tiles).  Inverse row transform, divide by sqrt(N) (image3.cpp:401-405),
 // magnitude, tile minimum and maximum (image3.cpp:402-411).  minmax[tile] = {min bits, max bits}
 // of non-negative floats, whose unsigned bit patterns order like the values.
+template <bool PAD>
 __global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, int RB, float scale,
                                                        const float2* __restrict__ tw,
                                                        const float2* __restrict__ spec,
@@ -422,15 +438,15 @@ __global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, i
     float2* x = (float2*)smem_raw;
     const int t = blockIdx.y, row0 = blockIdx.x * RB;
     const float2* in = spec + ((size_t)(t * 2) * h + row0) * w;
-    stage_contiguous<256, 4>(x, in, RB * w);
-    float2* stw = x + (size_t)RB * w;
+    stage_contiguous<256, 4, PAD>(x, in, RB * w);
+    float2* stw = x + (((size_t)xp<PAD>(RB * w) + 1) & ~(size_t)1);
     stage_contiguous<256, 2>(stw, tw, w / 2);
     __syncthreads();
-    fft_dit_inv<256>(x, logw, RB, stw);
+    fft_dit_inv<256, PAD>(x, logw, RB, stw);
     float* out = surf + ((size_t)t * h + row0) * w;
     float lo = INFINITY, hi = 0.f;
     for (int i = threadIdx.x; i < RB * w; i += 256) {
-        const float2 v = x[i];
+        const float2 v = x[xp<PAD>(i)];
         // cabs() of the complex float promoted to double (image3.cpp:407-410)
         const float m = (float)hypot((double)(v.x * scale), (double)(v.y * scale));
         out[i] = m;
@@ -970,6 +986,7 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
     unsigned long long* keys = (unsigned long long*)((char*)ws->meta + (((size_t)nt * 8 + 255) & ~(size_t)255));
     hipStream_t s = ctx->stream;
     const float scale = (float)(1.0 / sqrt((double)N));
+    size_t sh_rows = 0; bool pad_rows = false;      // LDS bytes and layout of the two row kernels
     ws->last_surface = fsurf;
 
     hipLaunchKernelGGL(xc_init_meta, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax, keys);
@@ -980,23 +997,32 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
         im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
         if (band) hipLaunchKernelGGL(xc_reset_minmax, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax);
         {
-            const size_t sh = ((size_t)p.RBw * w + w / 2) * sizeof(float2);
-            if (sh > 64 * 1024) {
-                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_rows_inv_abs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            // padded LDS layout whenever it fits (it does for every tile size but the largest)
+            const size_t nx = (size_t)p.RBw * w, nxp = ((nx + nx / 8 + 1) & ~(size_t)1);
+            const bool pad = (nx % 8 == 0) && (nxp + w / 2) * sizeof(float2) <= 160 * 1024;
+            sh_rows = ((pad ? nxp : nx) + w / 2) * sizeof(float2);
+            pad_rows = pad;
+            auto kf = pad ? xc_rows_fwd<true> : xc_rows_fwd<false>;
+            auto ki = pad ? xc_rows_inv_abs<true> : xc_rows_inv_abs<false>;
+            if (sh_rows > 64 * 1024) {
+                MIS_HIP(ctx, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_rows));
+                MIS_HIP(ctx, hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_rows));
             }
-            hipLaunchKernelGGL(xc_rows_fwd, dim3(h / p.RBw, 2, nt), dim3(256), sh, s, im, d_r1, d_r2, tile0,
+            hipLaunchKernelGGL(kf, dim3(h / p.RBw, 2, nt), dim3(256), sh_rows, s, im, d_r1, d_r2, tile0,
                                w, h, p.logw, p.RBw, tww, spec);
         }
         {
-            const size_t sh = ((size_t)2 * p.CB * h + h / 2) * sizeof(float2);
+            const size_t nx = (size_t)2 * p.CB * h, nxp = ((nx + nx / 8 + 1) & ~(size_t)1);
+            const bool pad = (nx % 8 == 0) && (nxp + h / 2) * sizeof(float2) <= 160 * 1024;
+            const size_t sh = ((pad ? nxp : nx) + h / 2) * sizeof(float2);
+            auto kc = pad ? xc_cols<true> : xc_cols<false>;
             if (sh > 64 * 1024)
-                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            hipLaunchKernelGGL(xc_cols, dim3(w / p.CB, nt), dim3(512), sh, s, w, h, p.logh, p.CB, scale, twh, spec);
+                MIS_HIP(ctx, hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            hipLaunchKernelGGL(kc, dim3(w / p.CB, nt), dim3(512), sh, s, w, h, p.logh, p.CB, scale, twh, spec);
         }
         {
-            const size_t sh = ((size_t)p.RBw * w + w / 2) * sizeof(float2);
-            hipLaunchKernelGGL(xc_rows_inv_abs, dim3(h / p.RBw, nt), dim3(256), sh, s, w, h, p.logw, p.RBw, scale,
+            auto ki = pad_rows ? xc_rows_inv_abs<true> : xc_rows_inv_abs<false>;
+            hipLaunchKernelGGL(ki, dim3(h / p.RBw, nt), dim3(256), sh_rows, s, w, h, p.logw, p.RBw, scale,
                                tww, spec, surf, minmax);
         }
         if (nbands > 1)
