@@ -722,20 +722,58 @@ __global__ __launch_bounds__(NT) void xg_dft_rows(float2* __restrict__ data, XgD
         }
         return;
     }
-    for (int i = threadIdx.x; i < d.M; i += NT) {
-        float2 v = make_float2(0.f, 0.f);
-        if (i < d.n) { v = row[i]; v.y *= sgn; v = cmul(v, d.chirp[i]); }
-        x[i] = v;
+    // Global operands are fetched U at a time with clamped indices and tested afterwards: a workgroup
+    // owns a CU's whole LDS here, so nothing else hides a load that is waited for on the spot.
+    constexpr int U = 8;
+    for (int base = threadIdx.x; base < d.M; base += NT * U) {
+        float2 v[U], c[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = min(base + NT * u, d.n - 1);
+            v[u] = row[i]; c[u] = d.chirp[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(c[u].x), "+v"(c[u].y));
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + NT * u;
+            if (i < d.M) {
+                float2 t = v[u]; t.y *= sgn;
+                x[i] = i < d.n ? cmul(t, c[u]) : make_float2(0.f, 0.f);
+            }
+        }
     }
     __syncthreads();
     fft_dif_fwd<NT>(x, d.logM, 1, d.tw);
-    for (int i = threadIdx.x; i < d.M; i += NT) x[i] = cmul(x[i], d.filt[i]);
+    for (int base = threadIdx.x; base < d.M; base += NT * U) {
+        float2 f[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) f[u] = d.filt[min(base + NT * u, d.M - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) asm volatile("" : "+v"(f[u].x), "+v"(f[u].y));
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + NT * u;
+            if (i < d.M) x[i] = cmul(x[i], f[u]);
+        }
+    }
     __syncthreads();
     fft_dit_inv<NT>(x, d.logM, 1, d.tw);
     const float inv_m = 1.0f / (float)d.M;
-    for (int i = threadIdx.x; i < d.n; i += NT) {
-        float2 v = cmul(x[i], d.chirp[i]);
-        row[i] = make_float2(v.x * inv_m, sgn * v.y * inv_m);
+    for (int base = threadIdx.x; base < d.n; base += NT * U) {
+        float2 c[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) c[u] = d.chirp[min(base + NT * u, d.n - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) asm volatile("" : "+v"(c[u].x), "+v"(c[u].y));
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + NT * u;
+            if (i < d.n) {
+                const float2 v = cmul(x[i], c[u]);
+                row[i] = make_float2(v.x * inv_m, sgn * v.y * inv_m);
+            }
+        }
     }
 }
 
@@ -784,17 +822,28 @@ __global__ __launch_bounds__(256) void xg_product(float2* __restrict__ spec, siz
 }
 
 // |c| / sqrt(N) and the tile extrema (image3.cpp:401-411), as in xc_rows_inv_abs
+#define XG_ABS_PER_THREAD 16     // elements per thread: fewer workgroups, fewer same-address atomics per tile
 __global__ __launch_bounds__(256) void xg_abs_minmax(const float2* __restrict__ spec, size_t N, float scale,
                                                      float* __restrict__ surf, unsigned* __restrict__ minmax)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i0 = (size_t)blockIdx.x * (256 * XG_ABS_PER_THREAD) + threadIdx.x;
     const int t = blockIdx.y;
+    const float2* sp = spec + (size_t)t * 2 * N;
     float lo = INFINITY, hi = 0.f;
-    if (i < N) {
-        const float2 v = spec[(size_t)t * 2 * N + i];
-        const float m = (float)hypot((double)(v.x * scale), (double)(v.y * scale));
-        surf[(size_t)t * N + i] = m;
-        lo = hi = m;
+    float2 v[XG_ABS_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < XG_ABS_PER_THREAD; k++) {      // clamped addresses: every load unconditional and in flight together
+        const size_t i = i0 + (size_t)256 * k;
+        v[k] = sp[i < N ? i : N - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < XG_ABS_PER_THREAD; k++) {
+        const size_t i = i0 + (size_t)256 * k;
+        const float m = (float)hypot((double)(v[k].x * scale), (double)(v[k].y * scale));
+        if (i < N) {
+            surf[(size_t)t * N + i] = m;
+            lo = fminf(lo, m); hi = fmaxf(hi, m);
+        }
     }
     lo = wave_min_f(lo); hi = wave_max_f(hi);
     tile_commit_minmax(minmax, t, lo, hi);
@@ -1080,7 +1129,7 @@ static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1
         rc = launch_dft(ctx, specT, dh, nt * w, w, 2 * N, 1); if (rc) return rc;
         hipLaunchKernelGGL(xg_transpose, dim3(tgridT.x, tgridT.y, nt), dim3(256), 0, s, specT, spec, w, h, 2 * N, 2 * N);
         rc = launch_dft(ctx, spec, dw, nt * h, h, 2 * N, 1); if (rc) return rc;
-        hipLaunchKernelGGL(xg_abs_minmax, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, spec, N, scale, surf, minmax);
+        hipLaunchKernelGGL(xg_abs_minmax, dim3((unsigned)((N + 256 * XG_ABS_PER_THREAD - 1) / (256 * XG_ABS_PER_THREAD)), nt), dim3(256), 0, s, spec, N, scale, surf, minmax);
         if (nbands > 1)
             hipLaunchKernelGGL(xc_band_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, N, minmax, surf, prod, band == 0);
     }
