@@ -703,7 +703,7 @@ struct XgDft { int n, M, logM, pow2; const float2* chirp; const float2* filt; co
 
 // In-place DFT of sequences of length d.n.  Sequence r lives at data + (r / per_batch) * batch_stride
 // + (r % per_batch) * n.  inverse != 0: unnormalised backward transform (conjugate, forward, conjugate).
-template <int NT>
+template <int NT, bool PAD>
 __global__ __launch_bounds__(NT) void xg_dft_rows(float2* __restrict__ data, XgDft d, int per_batch,
                                                    size_t batch_stride, int inverse)
 {
@@ -713,11 +713,11 @@ __global__ __launch_bounds__(NT) void xg_dft_rows(float2* __restrict__ data, XgD
     float2* row = data + (size_t)(r / per_batch) * batch_stride + (size_t)(r % per_batch) * d.n;
     const float sgn = inverse ? -1.f : 1.f;
     if (d.pow2) {
-        for (int i = threadIdx.x; i < d.n; i += NT) { float2 v = row[i]; v.y *= sgn; x[i] = v; }
+        for (int i = threadIdx.x; i < d.n; i += NT) { float2 v = row[i]; v.y *= sgn; x[xp<PAD>(i)] = v; }
         __syncthreads();
-        fft_dif_fwd<NT>(x, d.logM, 1, d.tw);
+        fft_dif_fwd<NT, PAD>(x, d.logM, 1, d.tw);
         for (int i = threadIdx.x; i < d.n; i += NT) {
-            float2 v = x[i]; v.y *= sgn;
+            float2 v = x[xp<PAD>(i)]; v.y *= sgn;
             row[d.logM ? bitrev(i, d.logM) : 0] = v;
         }
         return;
@@ -739,12 +739,12 @@ __global__ __launch_bounds__(NT) void xg_dft_rows(float2* __restrict__ data, XgD
             const int i = base + NT * u;
             if (i < d.M) {
                 float2 t = v[u]; t.y *= sgn;
-                x[i] = i < d.n ? cmul(t, c[u]) : make_float2(0.f, 0.f);
+                x[xp<PAD>(i)] = i < d.n ? cmul(t, c[u]) : make_float2(0.f, 0.f);
             }
         }
     }
     __syncthreads();
-    fft_dif_fwd<NT>(x, d.logM, 1, d.tw);
+    fft_dif_fwd<NT, PAD>(x, d.logM, 1, d.tw);
     for (int base = threadIdx.x; base < d.M; base += NT * U) {
         float2 f[U];
 #pragma unroll
@@ -754,11 +754,11 @@ __global__ __launch_bounds__(NT) void xg_dft_rows(float2* __restrict__ data, XgD
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = base + NT * u;
-            if (i < d.M) x[i] = cmul(x[i], f[u]);
+            if (i < d.M) x[xp<PAD>(i)] = cmul(x[xp<PAD>(i)], f[u]);
         }
     }
     __syncthreads();
-    fft_dit_inv<NT>(x, d.logM, 1, d.tw);
+    fft_dit_inv<NT, PAD>(x, d.logM, 1, d.tw);
     const float inv_m = 1.0f / (float)d.M;
     for (int base = threadIdx.x; base < d.n; base += NT * U) {
         float2 c[U];
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(NT) void xg_dft_rows(float2* __restrict__ data, XgD
         for (int u = 0; u < U; u++) {
             const int i = base + NT * u;
             if (i < d.n) {
-                const float2 v = cmul(x[i], c[u]);
+                const float2 v = cmul(x[xp<PAD>(i)], c[u]);
                 row[i] = make_float2(v.x * inv_m, sgn * v.y * inv_m);
             }
         }
@@ -983,13 +983,21 @@ static int get_dft(mis_ctx* ctx, int n, XgDft* d)
 
 static int launch_dft(mis_ctx* ctx, float2* data, const XgDft& d, int nseq, int per_batch, size_t batch_stride, int inverse)
 {
-    const size_t sh = (size_t)d.M * sizeof(float2);
-    if (sh > 64 * 1024)
-        MIS_HIP(ctx, hipFuncSetAttribute((const void*)xg_dft_rows<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    if (d.M >= 2048)
-        hipLaunchKernelGGL(xg_dft_rows<512>, dim3((unsigned)nseq), dim3(512), sh, ctx->stream, data, d, per_batch, batch_stride, inverse);
-    else
-        hipLaunchKernelGGL(xg_dft_rows<256>, dim3((unsigned)nseq), dim3(256), sh, ctx->stream, data, d, per_batch, batch_stride, inverse);
+    // padded LDS layout (see xp) whenever it fits
+    const bool pad = (d.M % 8 == 0) && ((size_t)d.M + d.M / 8) * sizeof(float2) <= 160 * 1024;
+    const size_t sh = ((size_t)d.M + (pad ? d.M / 8 : 0)) * sizeof(float2);
+    const dim3 grid((unsigned)nseq);
+#define XG_LAUNCH(NTV, PADV)                                                                                        \
+    do {                                                                                                            \
+        if (sh > 64 * 1024)                                                                                         \
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xg_dft_rows<NTV, PADV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
+        hipLaunchKernelGGL((xg_dft_rows<NTV, PADV>), grid, dim3(NTV), sh, ctx->stream, data, d, per_batch, batch_stride, inverse);       \
+    } while (0)
+    // a long sequence owns most of a CU's LDS, so its own workgroup has to bring the wavefronts that hide latency
+    if (d.M >= 8192) { if (pad) XG_LAUNCH(1024, true); else XG_LAUNCH(1024, false); }
+    else if (d.M >= 2048) { if (pad) XG_LAUNCH(512, true); else XG_LAUNCH(512, false); }
+    else             { if (pad) XG_LAUNCH(256, true); else XG_LAUNCH(256, false); }
+#undef XG_LAUNCH
     return MIS_OK;
 }
 
