@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+import mistereo
 import oracle
 import synth
 from ncc_util import compare_ncc, flat_mask
@@ -158,3 +159,41 @@ def test_random_shapes_windows_and_ranges(ctx, seed):
     if seed % 5 == 0:
         left[h // 3: h // 2, w // 4: w // 2] = left[0, 0]          # a flat patch
     _run(ctx, left, right, window, dmin, dmax)
+
+
+def test_back_to_back_calls_on_a_caller_stream():
+    """The 8-bit path forks small kernels onto an internal stream: three calls enqueued without any
+    synchronisation in between (two pairs, output tensors overwritten by the caller's own stream
+    work between the calls) must give what the same calls give one at a time."""
+    import torch
+    c = mistereo.Context(0)
+    try:
+        rng = np.random.default_rng(77)
+        pairs = []
+        for k in range(2):
+            left = synth.texture(300, 520, 900 + k)
+            right = synth.shift_right_image(left, synth.planar_disparity(300, 520, -12, 12, 8, 910 + k), fill_seed=920 + k)
+            pairs.append((torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()))
+        want = []
+        for tl, tr in pairs:                                   # one at a time, synchronised
+            c.bind_pair_torch(tl, tr)
+            d = torch.empty((300, 520), dtype=torch.float32, device="cuda"); p = torch.empty_like(d)
+            c.ncc_dense_torch(11, -70, 70, d, p)
+            c.synchronize()
+            want.append((d.clone(), p.clone()))
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            c.use_torch_stream()
+            d = torch.empty((300, 520), dtype=torch.float32, device="cuda"); p = torch.empty_like(d)
+            got = []
+            for rep in range(3):
+                tl, tr = pairs[rep % 2]
+                c.bind_pair_torch(tl, tr)
+                d.fill_(-5.0); p.fill_(-5.0)                   # caller's work on the same stream, same buffers
+                c.ncc_dense_torch(11, -70, 70, d, p)
+                got.append((d.clone(), p.clone()))             # ordered behind the call on the caller's stream
+            st.synchronize()
+        for rep in range(3):
+            assert torch.equal(got[rep][0], want[rep % 2][0]) and torch.equal(got[rep][1], want[rep % 2][1])
+    finally:
+        c.close()
