@@ -114,6 +114,9 @@ __device__ float tri_bound(float E)
     return f;
 }
 
+struct TriFast;
+__device__ double tri_error_bound(const TriFast& r, const float* t1p, const float* t2p, float z0, float lim);
+
 struct TriFast {
     float a1[3], a2[3];      // ray directions
     float nb, y;             // -ang2z, refined reciprocal of ang2z
@@ -135,6 +138,39 @@ __device__ __forceinline__ tri_f2 tri_s2(const TriFast& r, const float* t1p, con
     const tri_f2 w2y = z2 * r.a2[1] + t2p[1];
     const tri_f2 dx = w1x - w2x, dy = w1y - w2y;
     return dx * dx + dy * dy;
+}
+
+// Early end of a search loop.  In exact arithmetic the error of image3.cpp:102-132 is the length of a
+// vector that is linear in z (the second ray's parameter follows from equal heights), i.e. the
+// square root of a quadratic: convex, so once it has risen from one step to the next it keeps
+// rising in that direction.  The float evaluation differs from the exact one by at most
+// eps + 4u*err (u = 2^-24; eps from the rounding of every product, sum and the quotient, with the
+// magnitudes bounded over the whole range a loop can visit).  If two consecutive steps a, b of a
+// loop satisfy err_b - err_a > 2 (eps + 4u*err_b), the exact error rose, so every later step c has
+// float error >= exact_c - (..) >= exact_b - (..) > err_a >= smallest error so far: none of the
+// remaining steps (the reference runs about a hundred of them before it gives up) can change the
+// result, and the loop ends there.  The test is done on the sums of squares without a square root:
+// with D = s_b - s_a - 16u*s_b it is D > 0 and D^2 > 16 eps^2 s_b.  The value returned carries a
+// factor 2 of slack.
+__device__ double tri_error_bound(const TriFast& r, const float* t1p, const float* t2p, float z0, float lim)
+{
+    const double u = 5.9604644775390625e-08;
+    const double zm = fmax(fabs((double)z0), fabs((double)lim)) + 210.0;      // every z a loop can reach
+    const double m1x = zm * fabs((double)r.a1[0]) + fabs((double)t1p[0]);
+    const double m1y = zm * fabs((double)r.a1[1]) + fabs((double)t1p[1]);
+    const double m1z = zm * fabs((double)r.a1[2]) + fabs((double)t1p[2]);
+    const double e1x = 2.5 * u * m1x, e1y = 2.5 * u * m1y, e1z = 2.5 * u * m1z;   // product and sum of w1
+    const double an = m1z + fabs((double)t2p[2]);                             // |w1z - t2z|
+    const double ia = 1.0 / fabs((double)r.a2[2]);
+    const double z2m = an * ia * 1.000001;                                    // |z2|
+    const double ez2 = (e1z + 1.5 * u * an) * ia + 1.5 * u * z2m;             // difference, then the rounded quotient
+    const double m2x = z2m * fabs((double)r.a2[0]) + fabs((double)t2p[0]);
+    const double m2y = z2m * fabs((double)r.a2[1]) + fabs((double)t2p[1]);
+    const double e2x = fabs((double)r.a2[0]) * ez2 + 2.5 * u * m2x;
+    const double e2y = fabs((double)r.a2[1]) * ez2 + 2.5 * u * m2y;
+    const double edx = e1x + e2x + 1.5 * u * (m1x + m2x);
+    const double edy = e1y + e2y + 1.5 * u * (m1y + m2y);
+    return 2.0 * sqrt(edx * edx + edy * edy);
 }
 
 // cameras whose heights keep the quotient's operands in the plain range of the division sequence
@@ -192,9 +228,18 @@ __device__ void triangulate_point(const TriCam& c1, const TriCam& c2, bool cams_
     float zbest = 1000.0f;              // X, Y, Z hold the z = 1000 evaluation until a step improves on error0
     float bound = tri_bound(error0);
     const float lim = t1p[2];
+    // early end (see tri_error_bound): float test with 0.1 % slack on either side, far above the few
+    // ulp the test's own roundings can contribute; K = 16 eps^2
+    const double eps = tri_error_bound(r, t1p, t2p, z0, lim);
+    const float K = (float)(16.0 * eps * eps * 1.002);
+    auto rising = [&](float sa, float sb) -> bool {
+        const float D = fmaf(-17.0f * 5.9604644775390625e-08f, sb, (sb - sa) * 0.999f);
+        return D > 0.0f && D * D * 0.999f > K * sb;
+    };
     for (int dir = 0; dir < 2; dir++) {
         const float step = dir ? -1.0f : 1.0f;
         int counter = 0;
+        float smin = __builtin_inff();                         // smallest sum of squares among this loop's completed steps
         tri_f2 z = { z0, z0 + step };
         for (;;) {
             if (dir ? !(z.x > 0) : !(z.x < lim)) break;
@@ -204,6 +249,9 @@ __device__ void triangulate_point(const TriCam& c1, const TriCam& c2, bool cams_
             if (dir ? !(z.y > 0) : !(z.y < lim)) break;
             if (s.y <= bound) { counter = 0; zbest = z.y; bound = tri_bound(sqrtf(s.y)); }
             else if (counter++ > 100) break;
+            smin = fminf(smin, s.x);                           // NaN sums are ignored by fminf and fail the test below
+            if (rising(smin, s.y)) break;
+            smin = fminf(smin, s.y);
             z = (z + step) + step;
         }
     }

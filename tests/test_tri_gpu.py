@@ -119,3 +119,37 @@ def test_many_points_bit_exact(ctx):
     nan = np.isnan(want)
     assert np.array_equal(np.isnan(got), nan)
     assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+
+
+@pytest.mark.parametrize("geom", ["short_baseline", "utm_coordinates", "oblique"])
+def test_search_end_geometries(ctx, geom):
+    """Geometries in which the library ends a search loop early (steep error curves), cannot end it
+    early (coordinates of millions of metres: the rounding bound exceeds the slope), and oblique
+    views: the result is the reference's bit for bit in all of them."""
+    rng = np.random.default_rng(123)
+    A = [[10000, 0, 4096], [0, 10000, 4096], [0, 0, 1]]
+    def rot(ax, ay, az):
+        cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+        return (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+                @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    if geom == "short_baseline":
+        R1 = R2 = np.eye(3)
+        C1, C2 = np.array([0.0, 0.0, 3000.0]), np.array([60.0, 0.0, 3000.0])
+        dlo, dhi = 150, 260                       # ground at 2300 .. 4000 m below the cameras
+    elif geom == "utm_coordinates":
+        R1 = R2 = np.eye(3)
+        C1, C2 = np.array([512345.5, 4123456.25, 3000.0]), np.array([513245.5, 4123456.25, 3010.0])
+        dlo, dhi = 2500, 3500
+    else:
+        R1, R2 = rot(0.3, -0.2, 0.1), rot(0.25, -0.15, 0.05)
+        C1, C2 = np.array([0.0, 0.0, 2500.0]), np.array([400.0, 30.0, 2550.0])
+        dlo, dhi = 800, 2400
+    c1, c2 = (A, R1, -R1 @ C1), (A, R2, -R2 @ C2)
+    n = 60_000
+    u1 = rng.integers(0, 8192, n); v1 = rng.integers(0, 8192, n)
+    pts = np.stack([u1, v1, u1 - rng.integers(dlo, dhi + 1, n), v1 + rng.integers(-3, 4, n)], axis=1).astype(np.int32)
+    got = ctx.calculate_xyz(mistereo.make_camera(*c1), mistereo.make_camera(*c2), pts)
+    want = oracle.triangulate(oracle.make_camera(*c1), oracle.make_camera(*c2), pts)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
