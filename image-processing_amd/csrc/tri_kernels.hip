@@ -151,7 +151,7 @@ __device__ __forceinline__ tri_f2 tri_s2(const TriFast& r, const float* t1p, con
 // remaining steps (the reference runs about a hundred of them before it gives up) can change the
 // result, and the loop ends there.  The test is done on the sums of squares without a square root:
 // with D = s_b - s_a - 16u*s_b it is D > 0 and D^2 > 16 eps^2 s_b.  The value returned carries a
-// factor 2 of slack.
+// factor 1.25 of slack on top of the rounded-up constants.
 __device__ double tri_error_bound(const TriFast& r, const float* t1p, const float* t2p, float z0, float lim)
 {
     const double u = 5.9604644775390625e-08;
@@ -170,7 +170,7 @@ __device__ double tri_error_bound(const TriFast& r, const float* t1p, const floa
     const double e2y = fabs((double)r.a2[1]) * ez2 + 2.5 * u * m2y;
     const double edx = e1x + e2x + 1.5 * u * (m1x + m2x);
     const double edy = e1y + e2y + 1.5 * u * (m1y + m2y);
-    return 2.0 * sqrt(edx * edx + edy * edy);
+    return 1.25 * sqrt(edx * edx + edy * edy);
 }
 
 // cameras whose heights keep the quotient's operands in the plain range of the division sequence
