@@ -40,7 +40,23 @@ struct mis_ctx {
 
     // triangulation scratch
     void* tri_buf = nullptr; size_t tri_bytes = 0;
+
+    // host-buffer entry points: device-side result rasters (kept between calls) and the stream and
+    // events that copy finished row strips back while later strips are still being computed
+    void* out_buf = nullptr; size_t out_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t strip_done[8] = {};
+    void* pinned = nullptr;               // two staging slots of MIS_STAGE_BYTES each (page-locked)
+    hipEvent_t slot_ready[2] = {};
 };
+#define MIS_STAGE_BYTES ((size_t)32 << 20)
+
+// One piece of a device -> pageable host copy.
+struct MisCopyJob { void* dst; const void* src; size_t bytes; hipEvent_t after; };
+// Copies the jobs in order on ctx->copy_stream through the page-locked staging slots: the transfer
+// of one piece overlaps the host-side copy (several threads) of the previous one.  A job starts once
+// its `after` event (may be null) has completed.  Returns when everything has arrived.
+int mis_copy_back(mis_ctx* ctx, const MisCopyJob* jobs, int njobs);
 
 int mis_fail(mis_ctx* ctx, int code, const char* fmt, ...);
 #define MIS_HIP(ctx, call)                                                             \

@@ -6,6 +6,9 @@
 
 #include "mis_common.h"
 
+#include <string.h>
+#include <thread>
+
 #include <stdarg.h>
 #include <stdio.h>
 #include <mutex>
@@ -45,6 +48,60 @@ hipEvent_t mis_prof_mark(mis_ctx* ctx)
     hipEvent_t e = ctx->prof_events[ctx->prof_used++];
     (void)hipEventRecord(e, ctx->stream);
     return e;
+}
+
+// The runtime's own path for pageable destinations moves about 10 GB/s (one staging thread); page-locked
+// staging plus a few copying threads is several times that.
+static void host_copy_parallel(void* dst, const void* src, size_t bytes)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 4 : (nt > 8 ? 8 : nt);
+    if (bytes < ((size_t)4 << 20)) nt = 1;
+    if (nt == 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+    for (unsigned i = 0; i < nt; i++) {
+        const size_t o = (size_t)i * per;
+        if (o >= bytes) break;
+        const size_t m = bytes - o < per ? bytes - o : per;
+        th.emplace_back([=] { memcpy((char*)dst + o, (const char*)src + o, m); });
+    }
+    for (auto& t : th) t.join();
+}
+
+int mis_copy_back(mis_ctx* ctx, const MisCopyJob* jobs, int njobs)
+{
+    if (!ctx->copy_stream) MIS_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->pinned) {
+        MIS_HIP(ctx, hipHostMalloc(&ctx->pinned, 2 * MIS_STAGE_BYTES, hipHostMallocDefault));
+        for (int i = 0; i < 2; i++) MIS_HIP(ctx, hipEventCreateWithFlags(&ctx->slot_ready[i], hipEventDisableTiming));
+    }
+    hipStream_t cs = ctx->copy_stream;
+    // pieces in flight: (host destination, slot, bytes)
+    struct Piece { void* dst; int slot; size_t bytes; };
+    Piece pending = { nullptr, 0, 0 };
+    int slot = 0;
+    auto drain = [&](const Piece& p) -> int {
+        if (!p.dst) return MIS_OK;
+        MIS_HIP(ctx, hipEventSynchronize(ctx->slot_ready[p.slot]));
+        host_copy_parallel(p.dst, (char*)ctx->pinned + (size_t)p.slot * MIS_STAGE_BYTES, p.bytes);
+        return MIS_OK;
+    };
+    for (int j = 0; j < njobs; j++) {
+        if (jobs[j].after) MIS_HIP(ctx, hipStreamWaitEvent(cs, jobs[j].after, 0));
+        for (size_t o = 0; o < jobs[j].bytes; o += MIS_STAGE_BYTES) {
+            const size_t m = jobs[j].bytes - o < MIS_STAGE_BYTES ? jobs[j].bytes - o : MIS_STAGE_BYTES;
+            // the slot about to be refilled was drained one piece ago (two slots, one piece pending)
+            MIS_HIP(ctx, hipMemcpyAsync((char*)ctx->pinned + (size_t)slot * MIS_STAGE_BYTES, (const char*)jobs[j].src + o, m,
+                                        hipMemcpyDeviceToHost, cs));
+            MIS_HIP(ctx, hipEventRecord(ctx->slot_ready[slot], cs));
+            int rc = drain(pending);                      // host copy of the previous piece while this one travels
+            if (rc) return rc;
+            pending = { (char*)jobs[j].dst + o, slot, m };
+            slot ^= 1;
+        }
+    }
+    return drain(pending);
 }
 
 extern "C" {
@@ -119,6 +176,11 @@ int mis_destroy(mis_ctx* ctx)
     mis_ncc16_release(ctx);
     mis_xcorr_release(ctx);
     if (ctx->tri_buf) (void)hipFree(ctx->tri_buf);
+    if (ctx->out_buf) (void)hipFree(ctx->out_buf);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (hipEvent_t e : ctx->slot_ready) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->strip_done) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) if (ctx->owned_img[i]) (void)hipFree(ctx->owned_img[i]);
     for (void* p : ctx->owned_bands) (void)hipFree(p);

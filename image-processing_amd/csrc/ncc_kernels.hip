@@ -1286,26 +1286,47 @@ int mis_ncc_dense(mis_ctx* ctx, int window, int dmin, int dmax,
     if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "dense NCC: no image pair bound");
     if (!disp || !peak) return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: disp and peak outputs are required");
     MIS_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t n = (size_t)ctx->width * ctx->height;
-    float *dd = nullptr, *dp = nullptr, *dp2 = nullptr; int16_t* di = nullptr;
-    int rc = MIS_OK;
-    hipError_t e;
-    if ((e = hipMalloc((void**)&dd, n * 4)) != hipSuccess || (e = hipMalloc((void**)&dp, n * 4)) != hipSuccess ||
-        (idisp && (e = hipMalloc((void**)&di, n * 2)) != hipSuccess) ||
-        (peak2 && (e = hipMalloc((void**)&dp2, n * 4)) != hipSuccess)) {
-        rc = mis_fail(ctx, MIS_ERR_DEVICE, "dense NCC: output allocation failed: %s", hipGetErrorString(e));
+    const int H = ctx->height;
+    const size_t n = (size_t)ctx->width * H, rowpx = (size_t)ctx->width;
+    // device-side rasters, kept between calls
+    const size_t a4 = (n * 4 + 255) & ~(size_t)255, a2 = (n * 2 + 255) & ~(size_t)255;
+    int rc = mis_reserve(ctx, &ctx->out_buf, &ctx->out_bytes, 3 * a4 + a2);
+    if (rc) return rc;
+    float* dd = (float*)ctx->out_buf;
+    float* dp = (float*)((char*)ctx->out_buf + a4);
+    float* dp2 = peak2 ? (float*)((char*)ctx->out_buf + 2 * a4) : nullptr;
+    int16_t* di = idisp ? (int16_t*)((char*)ctx->out_buf + 3 * a4) : nullptr;
+    // The frame is computed in row strips and every finished strip is copied back on a second stream
+    // while the next ones are computed (the copy to host memory is longer than the computation).
+    constexpr int NS = 4;
+    if (!ctx->strip_done[0])
+        for (int i = 0; i < NS; i++) MIS_HIP(ctx, hipEventCreateWithFlags(&ctx->strip_done[i], hipEventDisableTiming));
+    int r0[NS + 1];
+    for (int i = 0; i <= NS; i++) r0[i] = (int)((long long)H * i / NS) & ~3;
+    r0[NS] = H;
+    for (int i = 0; i < NS && !rc; i++) {
+        if (r0[i + 1] <= r0[i]) continue;
+        rc = ncc_run(ctx, window, dmin, dmax, r0[i], r0[i + 1] - r0[i], dd, dp, di, dp2);
+        if (!rc) MIS_HIP(ctx, hipEventRecord(ctx->strip_done[i], ctx->stream));
     }
-    if (!rc) rc = ncc_run(ctx, window, dmin, dmax, 0, ctx->height, dd, dp, di, dp2);
+    hipError_t e = hipSuccess;
     if (!rc) {
-        hipStream_t s = ctx->stream;
-        e = hipMemcpyAsync(disp, dd, n * 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(peak, dp, n * 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess && idisp) e = hipMemcpyAsync(idisp, di, n * 2, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess && peak2) e = hipMemcpyAsync(peak2, dp2, n * 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "dense NCC: copy back failed: %s", hipGetErrorString(e));
+        MisCopyJob jobs[4 * NS];
+        int nj = 0;
+        for (int i = 0; i < NS; i++) {
+            if (r0[i + 1] <= r0[i]) continue;
+            const size_t o = (size_t)r0[i] * rowpx, m = (size_t)(r0[i + 1] - r0[i]) * rowpx;
+            jobs[nj++] = { disp + o, dd + o, m * 4, ctx->strip_done[i] };
+            jobs[nj++] = { peak + o, dp + o, m * 4, nullptr };
+            if (idisp) jobs[nj++] = { idisp + o, di + o, m * 2, nullptr };
+            if (peak2) jobs[nj++] = { peak2 + o, dp2 + o, m * 4, nullptr };
+        }
+        rc = mis_copy_back(ctx, jobs, nj);
     }
-    (void)hipFree(dd); (void)hipFree(dp); (void)hipFree(di); (void)hipFree(dp2);
+    if (ctx->copy_stream) e = hipStreamSynchronize(ctx->copy_stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = e2;
+    if (!rc && e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "dense NCC: copy back failed: %s", hipGetErrorString(e));
     return rc;
 }
 
