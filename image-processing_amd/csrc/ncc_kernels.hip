@@ -1002,11 +1002,17 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
         if (m == 0) continue;                     // wave-uniform: a wavefront is one row
         const uint32_t* plq = pl + qi * LC;
         const uint32_t* prq = pr + qi * NC;
-        uint32_t rc = prq[0], rb = prq[1];
+        // the row's LDS address goes through a register of its own: folded into one base for all quad
+        // rows, the column offsets outgrow the 8-bit fields of ds_read2 and every read costs an add
+        typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+        uint32_t a32 = (uint32_t)(uintptr_t)(lds_u32_ptr)prq;
+        asm volatile("" : "+v"(a32));
+        const lds_u32_ptr prq3 = (lds_u32_ptr)(uintptr_t)a32;
+        uint32_t rc = prq3[0], rb = prq3[1];
         if (m == 0xFFFFFFFFu) {                   // all four rows of the quad lie in the window: no masking
 #pragma unroll
             for (int i = 0; i <= 2 * R; i++) {
-                const uint32_t ra = prq[i + 2];
+                const uint32_t ra = prq3[i + 2];
                 const uint32_t l = plq[i];
                 Sm = __builtin_amdgcn_sdot4((int)l, (int)ra, Sm, false);
                 S0 = __builtin_amdgcn_sdot4((int)l, (int)rb, S0, false);
@@ -1016,7 +1022,7 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
         } else {
 #pragma unroll
             for (int i = 0; i <= 2 * R; i++) {
-                const uint32_t ra = prq[i + 2];
+                const uint32_t ra = prq3[i + 2];
                 const uint32_t l = plq[i] & m;
                 Sm = __builtin_amdgcn_sdot4((int)l, (int)ra, Sm, false);
                 S0 = __builtin_amdgcn_sdot4((int)l, (int)rb, S0, false);
