@@ -201,6 +201,24 @@ __device__ void triangulate_point(const TriCam& c1, const TriCam& c2, bool cams_
     float z1 = 1000.0f;
     const float error1 = xyz2(r.a1, t1p, r.a2, t2p, z1, X, Y, Z);
     z0 = z0 + ((z1 - z0) / (error1 - error0) * (0 - error0));          // image3.cpp:216
+    // Degenerate starts (parallel or nearly parallel rays: the secant step above divides by a zero or
+    // tiny difference).  NaN: neither loop runs.  +-infinity: every step evaluates to infinity or NaN,
+    // which never compares below the smallest error so far, so the z = 1000 result stands.
+    // |z0| >= 2^25: z +- 1.0f rounds back to z, so every step of a loop is the same evaluation and only
+    // the first can change anything.
+    if (!(fabsf(z0) <= 3.0e38f)) return;
+    if (fabsf(z0) >= 33554432.0f) {
+        float X1, Y1, Z1, min_error = error0;
+        if (z0 < t1p[2]) {
+            const float e = xyz2(r.a1, t1p, r.a2, t2p, z0, X1, Y1, Z1);
+            if (e < min_error) { min_error = e; X = X1; Y = Y1; Z = Z1; }
+        }
+        if (z0 > 0) {
+            const float e = xyz2(r.a1, t1p, r.a2, t2p, z0, X1, Y1, Z1);
+            if (e < min_error) { min_error = e; X = X1; Y = Y1; Z = Z1; }
+        }
+        return;
+    }
     if (!(cams_fast && tri_fast_ok(r.a1[2], r.a2[2], z0))) {
         // same search, general arithmetic
         float X1, Y1, Z1, min_error = error0;
