@@ -64,7 +64,12 @@ static void host_copy_parallel(void* dst, const void* src, size_t bytes)
         const size_t o = (size_t)i * per;
         if (o >= bytes) break;
         const size_t m = bytes - o < per ? bytes - o : per;
-        th.emplace_back([=] { memcpy((char*)dst + o, (const char*)src + o, m); });
+        // no exception may leave the library: a part whose thread cannot be started is copied here
+        try {
+            th.emplace_back([=] { memcpy((char*)dst + o, (const char*)src + o, m); });
+        } catch (...) {
+            memcpy((char*)dst + o, (const char*)src + o, m);
+        }
     }
     for (auto& t : th) t.join();
 }
