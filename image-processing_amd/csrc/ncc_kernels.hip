@@ -1245,7 +1245,15 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     if (a.row0 >= a.row1) { mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx); return ncc_join(ctx, w); }
     const int nd = dmax - dmin + 1;
     const int total_chunks = (nd + 63) / 64;
+    // Rows per workgroup: every band re-runs the column sums of the 2r rows above it, so taller bands
+    // do less work (256 rows: 12.0 ms at 8192x8192, +-256 against 12.15 with 128; 384 and 512 leave too
+    // few, uneven rounds of wavefronts: 12.5 and 12.35), as long as the grid still has several rounds of
+    // wavefronts for the 5120 wave slots of the chip.
     a.band_rows = 128;
+    if (!d_peak2) {
+        const long long strips = (W - 2 * r + 31) / 32, bands256 = (a.row1 - a.row0 + 255) / 256;
+        if (strips * bands256 * (nd / 64 > 0 ? nd / 64 : 1) >= 6 * 5120) a.band_rows = 256;
+    }
 
     // a workgroup holds at most 16 wavefronts: wider ranges would need a merge across
     // workgroups, which this build does not have
