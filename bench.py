@@ -56,14 +56,15 @@ def issue_floor(W, H, window, nd, kernel_s):
     """Time the argmax kernel's own instruction mix needs at full vector-issue rate, for the 21x21
     window: 509 ns of SIMD time per strip row (32 columns x 64 disparities; per-instruction prices
     measured with tools/ubench/valu_rates on this part: dot2c 94, DPP maxima 93, sliding sums 89,
-    packed fmas 86, keys 58, rest 90), 1024 SIMDs, 128-row bands with 2r warm-up rows."""
+    packed fmas 86, keys 58, rest 90), 1024 SIMDs, 256- or 128-row bands with 2r warm-up rows."""
     if window != 21:
         return None
     r = window // 2
     strips = -(-(W - 2 * r) // 32)
     rows = H - 2 * r
-    bands = -(-rows // 128)
     chunks = nd // 64
+    band = 256 if strips * -(-rows // 256) * max(chunks, 1) >= 6 * 5120 else 128      # the library's rule
+    bands = -(-rows // band)
     strip_rows = strips * chunks * (rows + bands * 2 * r * 0.37)      # warm-up rows run the column sums only (37 % of a row)
     floor_s = strip_rows * 509e-9 / 1024
     return {"ms": round(floor_s * 1e3, 3), "frac": round(floor_s / kernel_s, 3) if kernel_s > 0 else None,
