@@ -1224,8 +1224,11 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
         a.out_pitch = W;
         a.nstrips = a.nbands = 0;
         a.nchunk = (dmax - dmin + 1 + 63) / 64;
-        a.band_rows = 128;
         if (a.row0 >= a.row1) { mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
+        {   // taller bands (less warm-up work per output row) when the grid still fills the 3072 wave slots several times
+            const long long strips = (W - 2 * r + 31) / 32, bands256 = (a.row1 - a.row0 + 255) / 256;
+            a.band_rows = strips * bands256 * a.nchunk >= 6 * 3072 ? 256 : 128;
+        }
         return mis_ncc16_run(ctx, window, a, d_disp, d_peak, d_idisp);
     }
     if (ctx->dtype != MIS_U8)
