@@ -906,6 +906,9 @@ __global__ __launch_bounds__(NCC_TAIL_NT) void ncc_tail_kernel(
 // columns of the run and the right columns of the run for the WHOLE search range, and each pixel
 // then reads its 2R+1 left and 2R+3 right columns from LDS.
 #define NCC_REF_BW 128
+#ifndef NCC_REFINE_KEY_BATCH
+#define NCC_REFINE_KEY_BATCH 5
+#endif
 template <int R>
 struct NccRefineCfg {
     static constexpr int NQ = (2 * R + 7) / 4 + 1;       // quad rows the windows of 4 consecutive rows can touch
@@ -941,12 +944,13 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     if (inside) {
         float best = -1.0e30f;                     // below any score, above the bias of masked lanes
         const size_t plane = (size_t)a.H * a.out_pitch;
-        for (int c0 = 0; c0 < nchunk; c0 += 4) {   // four planes per round trip: the loads are independent
-            float k4[4];
+        constexpr int NKB = NCC_REFINE_KEY_BATCH;  // planes per round trip (independent loads)
+        for (int c0 = 0; c0 < nchunk; c0 += NKB) {
+            float k4[NKB];
 #pragma unroll
-            for (int i = 0; i < 4; i++) k4[i] = gKeys[(size_t)min(c0 + i, nchunk - 1) * plane + o];
+            for (int i = 0; i < NKB; i++) k4[i] = gKeys[(size_t)min(c0 + i, nchunk - 1) * plane + o];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NKB; i++) {
                 const uint32_t kb = __builtin_bit_cast(uint32_t, k4[i]);
                 const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
                 if (c0 + i < nchunk && v > best) { best = v; ds = a.dmin + (c0 + i) * 64 + 63 - (int)(kb & 63u); }
