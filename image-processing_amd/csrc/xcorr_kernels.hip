@@ -606,6 +606,12 @@ __global__ __launch_bounds__(256) void xc_colblur_argmax(int w, int h, const flo
     // and adds the pairs outward with separate multiply and add
     constexpr int NR = XC_RB5 / 4;
     const int j0 = rg * NR;
+    // the thread's samples of the normalised surface, requested now (clamped coordinates, tested at
+    // the end) so that they travel during the blur instead of one exposed round trip each after it
+    float sf[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+        sf[i] = surf[(size_t)t * h * w + (size_t)min(y0 + j0 + i, h - 1) * w + min(x, w - 1)];
     float acc[NR];
     if (kh == 1) {
 #pragma unroll
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(256) void xc_colblur_argmax(int w, int h, const flo
         const int y = y0 + j0 + i;
         if (x >= w || y >= h) continue;
         const size_t o = (size_t)t * h * w + (size_t)y * w + x;
-        const float imout = (x < w2 && y < h2) ? surf[o] : 0.f;
+        const float imout = (x < w2 && y < h2) ? sf[i] : 0.f;
         const float dog = __fsub_rn(imout, acc[i]);
         if (dog_out) dog_out[o] = dog;
         if (x < w2 && y < h2 && dog > -1.0f) {
