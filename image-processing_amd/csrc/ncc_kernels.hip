@@ -1037,14 +1037,22 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     }
 
     const float nc = gNegc[(size_t)y * P + (x - R)], ng = gNegg[(size_t)y * P + (x - R)], il = gIL[(size_t)y * P + (x - R)];
-    auto score = [&](int S, int col, int d) -> float {
+    // the right-image tables of the three candidates: six loads issued together (clamped columns), the
+    // range tests applied afterwards; loads inside the tests would be three more exposed round trips
+    float srv3[3], irv3[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int col = min(max(u + 1 - k, 0), a.W - 1);
+        srv3[k] = gRsr[(size_t)y * P + col];
+        irv3[k] = gRir[(size_t)y * P + col];
+    }
+    auto score = [&](int S, int k, int col, int d) -> float {
         if (d < a.dmin || d > a.dmax || col < 0 || col >= a.W) return __builtin_nanf("");
-        const float srv = gRsr[(size_t)y * P + col];
-        const float tt = __builtin_fmaf(nc, srv, (float)S);
-        const float cov = __builtin_fmaf(ng, srv, tt);
-        return __builtin_fmaf(cov, gRir[(size_t)y * P + col], 0.f);      // NaN where the window does not fit
+        const float tt = __builtin_fmaf(nc, srv3[k], (float)S);
+        const float cov = __builtin_fmaf(ng, srv3[k], tt);
+        return __builtin_fmaf(cov, irv3[k], 0.f);                        // NaN where the window does not fit
     };
-    const float sm = score(Sm, u + 1, ds - 1), s0 = score(S0, u, ds), sp = score(Sp, u - 1, ds + 1);
+    const float sm = score(Sm, 0, u + 1, ds - 1), s0 = score(S0, 1, u, ds), sp = score(Sp, 2, u - 1, ds + 1);
     float delta = 0.f;
     if (sm == sm && sp == sp) {
         const float den = 2.f * (sm - 2.f * s0 + sp);
