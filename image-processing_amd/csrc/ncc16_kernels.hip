@@ -384,12 +384,20 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
     constexpr double NN = (double)((2 * R + 1) * (2 * R + 1));
     const double sl = (double)gSL[(size_t)y * P + (x - R)];
     const float il = gIL[(size_t)y * P + (x - R)];
-    auto score = [&](double S, int col, int d) -> float {
+    // table values of the three candidates: loaded together (clamped columns), range tests afterwards
+    int srv[3]; float irv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int col = min(max(u + 1 - k, 0), a.W - 1);
+        srv[k] = gSR[(size_t)y * P + col];
+        irv[k] = gIR[(size_t)y * P + col];
+    }
+    auto score = [&](double S, int k, int col, int d) -> float {
         if (d < a.dmin || d > a.dmax || col < 0 || col >= a.W) return __builtin_nanf("");
-        const double num = __builtin_fma(NN, S, -(sl * (double)gSR[(size_t)y * P + col]));
-        return __builtin_fmaf((float)num, gIR[(size_t)y * P + col], 0.f);
+        const double num = __builtin_fma(NN, S, -(sl * (double)srv[k]));
+        return __builtin_fmaf((float)num, irv[k], 0.f);
     };
-    const float sm = score(Sm, u + 1, ds - 1), s0 = score(S0, u, ds), sp = score(Sp, u - 1, ds + 1);
+    const float sm = score(Sm, 0, u + 1, ds - 1), s0 = score(S0, 1, u, ds), sp = score(Sp, 2, u - 1, ds + 1);
     float delta = 0.f;
     if (sm == sm && sp == sp) {
         const float den = 2.f * (sm - 2.f * s0 + sp);
