@@ -73,6 +73,9 @@ int mis_reserve(mis_ctx* ctx, void** buf, size_t* cap, size_t bytes);
 // next event of the profiling pool, recorded on the context's stream (nullptr: profiling off)
 hipEvent_t mis_prof_mark(mis_ctx* ctx);
 
+// looks up, once per device, the address of the triangulation's statically allocated counter slots
+int mis_tri_init_device(mis_ctx* ctx);
+
 void mis_ncc_release(mis_ctx* ctx);
 void mis_ncc16_release(mis_ctx* ctx);
 void mis_xcorr_release(mis_ctx* ctx);

@@ -168,6 +168,12 @@ int mis_create(int device_id, mis_ctx** out)
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return mis_fail(nullptr, MIS_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
+    if (mis_tri_init_device(c) != MIS_OK) {
+        const std::string msg = c->err;
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return mis_fail(nullptr, MIS_ERR_DEVICE, "mis_create: %s", msg.c_str());
+    }
     *out = c;
     return MIS_OK;
 }

@@ -9,6 +9,7 @@
 #include "mis_common.h"
 
 #include <math.h>
+#include <mutex>
 
 struct TriCam {
     float Rp[9];   // R^-1
@@ -324,6 +325,37 @@ __global__ __launch_bounds__(256) void tri_disparity_kernel(TriCam c1, TriCam c2
     }
 }
 
+// Sum of the spread counters -> one device word (the count of the entry point that allocates nothing).
+__global__ __launch_bounds__(64) void tri_count_sum_kernel(const unsigned long long* __restrict__ count, long long* __restrict__ out)
+{
+    unsigned long long v = count[threadIdx.x * 16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (threadIdx.x == 0) *out = (long long)v;
+}
+
+// Counter slots of mis_triangulate_disparity_noalloc: device memory that exists from the moment the
+// library is loaded, one copy per GPU, held until the process ends (8 KB).  In host code the name
+// below is only a handle for hipGetSymbolAddress; kernels and memsets get the address looked up by
+// mis_tri_init_device for the device they run on.
+static __device__ __align__(256) unsigned long long scratch[TRI_COUNT_SLOTS * 16];
+#define TRI_MAX_DEVICES 64
+static unsigned long long* g_tri_scratch[TRI_MAX_DEVICES];      // per device, filled by mis_tri_init_device
+static std::mutex g_tri_mu;
+
+// called by mis_create with ctx->device current
+int mis_tri_init_device(mis_ctx* ctx)
+{
+    if (ctx->device < 0 || ctx->device >= TRI_MAX_DEVICES) return MIS_OK;     // the no-alloc entry point reports it
+    std::lock_guard<std::mutex> g(g_tri_mu);
+    if (!g_tri_scratch[ctx->device]) {
+        void* p = nullptr;
+        MIS_HIP(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_tri_scratch[ctx->device] = (unsigned long long*)p;
+    }
+    return MIS_OK;
+}
+
 static int tri_check(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2)
 {
     if (!ctx) return MIS_ERR_ARG;
@@ -396,6 +428,33 @@ int mis_triangulate_disparity_device(mis_ctx* ctx, const mis_camera* c1, const m
         for (int i = 0; i < TRI_COUNT_SLOTS; i++) total += h[i * 16];
         *n_matched = (long long)total;
     }
+    return MIS_OK;
+}
+
+int mis_triangulate_disparity_noalloc(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                                      const float* d_disp, const float* d_peak, float min_peak,
+                                      int width, int height, float* d_xyz, long long* d_n_matched)
+{
+    int rc = tri_check(ctx, c1, c2);
+    if (rc) return rc;
+    if (!d_disp || !d_peak || !d_xyz) return mis_fail(ctx, MIS_ERR_ARG, "triangulate (no-alloc): NULL buffer");
+    if (width <= 0 || height <= 0 || width > MIS_NOALLOC_MAX_WIDTH || height > MIS_NOALLOC_MAX_HEIGHT)
+        return mis_fail(ctx, MIS_ERR_ARG, "triangulate (no-alloc): raster %d x %d outside the supported 1..%d x 1..%d",
+                        width, height, MIS_NOALLOC_MAX_WIDTH, MIS_NOALLOC_MAX_HEIGHT);
+    if (ctx->device < 0 || ctx->device >= TRI_MAX_DEVICES)
+        return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "triangulate (no-alloc): device %d beyond the %d devices this entry point keeps scratch for",
+                        ctx->device, TRI_MAX_DEVICES);
+    unsigned long long* cnt = g_tri_scratch[ctx->device];       // looked up once per device by mis_create
+    if (!cnt) return mis_fail(ctx, MIS_ERR_STATE, "triangulate (no-alloc): scratch address of device %d unknown", ctx->device);
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    // the array keeps the previous call's counts
+    MIS_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)TRI_COUNT_SLOTS * 128, ctx->stream));
+    TriCam a = make_cam(c1), b = make_cam(c2);
+    hipLaunchKernelGGL(tri_disparity_kernel, dim3((width + 255) / 256, height), dim3(256), 0, ctx->stream, a, b,
+                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, width, height, d_xyz, cnt);
+    if (d_n_matched)
+        hipLaunchKernelGGL(tri_count_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt, d_n_matched);
+    MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
 

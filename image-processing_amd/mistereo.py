@@ -52,6 +52,7 @@ EXPORTS = [
     "mis_xcorr_tiles", "mis_xcorr_tiles_device", "mis_xcorr_tile_surfaces",
     "mis_fft2d_forward", "mis_xcorr_surface_u8",
     "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
+    "mis_triangulate_disparity_noalloc",
     "mis_disparity_map", "mis_write_xyz", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
     "mis_set_extra_bands_device", "mis_upload_extra_bands", "mis_masked_peak",
     "mis_profile_enable", "mis_profile_read", "mis_version",
@@ -101,6 +102,7 @@ def load_library():
         lib.mis_profile_enable.argtypes = [vp, i32]
         lib.mis_profile_read.argtypes = [vp, vp, vp, vp, vp]
         lib.mis_triangulate_disparity_device.argtypes = [vp, vp, vp, vp, vp, f32, vp, vp]
+        lib.mis_triangulate_disparity_noalloc.argtypes = [vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]
         _lib = lib
     return _lib
 
@@ -387,3 +389,11 @@ class Context:
                                                                _dev_ptr(peak), C.c_float(min_peak), _dev_ptr(xyz),
                                                                C.byref(n) if count else None))
         return n.value if count else None
+
+    def triangulate_disparity_noalloc_torch(self, cam1, cam2, disp, peak, min_peak, xyz, n_matched=None):
+        """The entry point that allocates nothing: raster size from the tensors, the matched count is
+        written to the int64 CUDA tensor n_matched (optional); nothing is synchronised."""
+        h, w = disp.shape
+        self._check(self._lib.mis_triangulate_disparity_noalloc(self._h, C.byref(cam1), C.byref(cam2), _dev_ptr(disp),
+                                                                _dev_ptr(peak), C.c_float(min_peak), w, h,
+                                                                _dev_ptr(xyz), _dev_ptr(n_matched)))

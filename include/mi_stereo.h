@@ -153,6 +153,22 @@ int mis_triangulate_disparity_device(mis_ctx* ctx, const mis_camera* c1, const m
                                      const float* d_disp, const float* d_peak, float min_peak,
                                      float* d_xyz, long long* n_matched);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same computation as
+ * mis_triangulate_disparity_device, but the raster size is passed in (no pair needs to be bound), the
+ * matched count goes to DEVICE memory (d_n_matched, nullable) without synchronising, and the per-call
+ * counter slots live in an 8 KB statically allocated device array (one copy per GPU, held until the
+ * process ends) instead of context memory: the call makes no hipMalloc / hipFree and only enqueues
+ * on the context's stream.  Limits: width <= MIS_NOALLOC_MAX_WIDTH, height <= MIS_NOALLOC_MAX_HEIGHT
+ * (MIS_ERR_ARG beyond them).  All calls on one GPU share that array (it is cleared at the start of
+ * every call): calls that overlap in time on one GPU, from any context or stream, race on the count;
+ * the XYZ output does not depend on it. */
+#define MIS_NOALLOC_MAX_WIDTH 65536
+#define MIS_NOALLOC_MAX_HEIGHT 65535
+int mis_triangulate_disparity_noalloc(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                                      const float* d_disp, const float* d_peak, float min_peak,
+                                      int width, int height, float* d_xyz, long long* d_n_matched);
+
 /* ---- coarse-to-fine driver and output records (host code above the kernels) -------------------
  * One leaf of the tile recursion: what calcDisparityMap hands to its outputs (image3.cpp:812-861). */
 typedef struct {
