@@ -253,6 +253,14 @@ int mis_bind_pair_device(mis_ctx* ctx, const void* d_img1, const void* d_img2, i
     return MIS_OK;
 }
 
+int mis_invalidate_pair(mis_ctx* ctx)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "invalidate: no image pair bound");
+    ctx->pair_serial++;             // every table derived from the rasters is rebuilt by the next call that needs it
+    return MIS_OK;
+}
+
 int mis_upload_pair(mis_ctx* ctx, const void* img1, const void* img2, int dtype,
                     int width, int height, size_t row_stride_bytes)
 {
@@ -262,6 +270,13 @@ int mis_upload_pair(mis_ctx* ctx, const void* img1, const void* img2, int dtype,
     size_t rowb = (size_t)width * mis_pixel_bytes(dtype);
     size_t bytes = rowb * height;
     if (ctx->owned_img_bytes < bytes) {
+        // the bound pair may be these very buffers: unbind before they are freed, so that a failed
+        // allocation below leaves the context without a pair instead of with dangling pointers
+        if (ctx->img[0] == ctx->owned_img[0] || ctx->img[1] == ctx->owned_img[1]) {
+            drop_extra_bands(ctx);
+            ctx->img[0] = ctx->img[1] = nullptr;
+            ctx->pair_serial++;
+        }
         for (int i = 0; i < 2; i++) {
             if (ctx->owned_img[i]) { MIS_HIP(ctx, hipFree(ctx->owned_img[i])); ctx->owned_img[i] = nullptr; }
         }
@@ -301,23 +316,32 @@ int mis_upload_extra_bands(mis_ctx* ctx, int n_extra, const void* const* img1, c
     const size_t rowb = (size_t)ctx->width * mis_pixel_bytes(ctx->dtype);
     if (row_stride_bytes < rowb) return mis_fail(ctx, MIS_ERR_ARG, "extra bands: row stride smaller than a row");
     if (ctx->stride != rowb) return mis_fail(ctx, MIS_ERR_STATE, "extra bands: the bound pair must be tightly packed (upload it with mis_upload_pair)");
+    for (int i = 0; i < n_extra; i++)
+        if (!img1[i] || !img2[i]) return mis_fail(ctx, MIS_ERR_ARG, "extra bands: band %d is NULL", i + 2);
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     drop_extra_bands(ctx);
-    for (int i = 0; i < n_extra; i++) {
+    // every failure below leaves the context without extra bands (never with lists of unequal length)
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n_extra && e == hipSuccess; i++) {
         const void* src[2] = { img1[i], img2[i] };
-        for (int s = 0; s < 2; s++) {
-            if (!src[s]) return mis_fail(ctx, MIS_ERR_ARG, "extra bands: band %d is NULL", i + 2);
+        for (int s = 0; s < 2 && e == hipSuccess; s++) {
             void* d = nullptr;
-            MIS_HIP(ctx, hipMalloc(&d, rowb * ctx->height));
+            e = hipMalloc(&d, rowb * ctx->height);
+            if (e != hipSuccess) break;
             ctx->owned_bands.push_back(d);
             if (row_stride_bytes == rowb)
-                MIS_HIP(ctx, hipMemcpyAsync(d, src[s], rowb * ctx->height, hipMemcpyHostToDevice, ctx->stream));
+                e = hipMemcpyAsync(d, src[s], rowb * ctx->height, hipMemcpyHostToDevice, ctx->stream);
             else
-                MIS_HIP(ctx, hipMemcpy2DAsync(d, rowb, src[s], row_stride_bytes, rowb, ctx->height, hipMemcpyHostToDevice, ctx->stream));
+                e = hipMemcpy2DAsync(d, rowb, src[s], row_stride_bytes, rowb, ctx->height, hipMemcpyHostToDevice, ctx->stream);
             ctx->band_img[s].push_back(d);
         }
     }
-    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) {
+        drop_extra_bands(ctx);
+        return mis_fail(ctx, MIS_ERR_DEVICE, "extra bands: upload failed: %s", hipGetErrorString(e));
+    }
     return MIS_OK;
 }
 

@@ -19,6 +19,8 @@ struct Ncc16Ws {
     size_t cap_px = 0;
     int pitch = 0, rows = 0, window = 0;
     uint64_t pair_serial = 0;
+    hipEvent_t ev_built = nullptr;              // end of the table build on built_stream (see ncc_kernels.hip)
+    hipStream_t built_stream = nullptr;
 };
 
 void mis_ncc16_release(mis_ctx* ctx)
@@ -27,6 +29,7 @@ void mis_ncc16_release(mis_ctx* ctx)
     if (!w) return;
     void* bufs[] = { w->L32, w->R32, w->SL, w->SR, w->iL, w->iR, w->hs1, w->hs2, w->keys, w->Ld, w->SLd };
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (w->ev_built) (void)hipEventDestroy(w->ev_built);
     delete w;
     ctx->ncc16 = nullptr;
 }
@@ -426,7 +429,10 @@ static int ncc16_prepare(mis_ctx* ctx, int window)
         w->cap_px = npx;
         w->pair_serial = 0;
     }
-    if (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H) return MIS_OK;
+    if (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H) {
+        if (w->built_stream != ctx->stream && w->ev_built) MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, w->ev_built, 0));
+        return MIS_OK;
+    }
     w->pitch = pitch; w->rows = H;
     dim3 grid((pitch + 255) / 256, H), block(256);
     dim3 sgrid((pitch + 255) / 256, (H + NCC16_STATS_BAND - 1) / NCC16_STATS_BAND);
@@ -437,6 +443,9 @@ static int ncc16_prepare(mis_ctx* ctx, int window)
     hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[1], stride_px, W, H, r, pitch, w->R32, (double*)nullptr, w->hs1, w->hs2);
     hipLaunchKernelGGL(ncc16_stats_kernel<false>, sgrid, block, 0, s, W, H, r, pitch, w->hs1, w->hs2, w->SR, w->iR, (double*)nullptr);
     MIS_HIP(ctx, hipGetLastError());
+    if (!w->ev_built) MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_built, hipEventDisableTiming));
+    MIS_HIP(ctx, hipEventRecord(w->ev_built, ctx->stream));
+    w->built_stream = ctx->stream;
     w->pair_serial = ctx->pair_serial;
     w->window = window;
     return MIS_OK;

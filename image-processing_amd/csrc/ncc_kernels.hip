@@ -48,6 +48,12 @@ struct NccWs {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_tables = nullptr, ev_join = nullptr;
     bool forked = false;        // the side stream carries work of the current call
+    // The tables are built by the first call after a bind and reused by later calls, which may come
+    // on another stream (mis_set_stream): ev_built marks the end of the building call on the stream
+    // it ran on, and a reusing call on a different stream waits for it.
+    hipEvent_t ev_built = nullptr;
+    hipStream_t built_stream = nullptr;
+    bool building = false;      // the current call builds the tables
 };
 
 // side stream of the current call (created on first use), ordered behind everything enqueued on the main stream so far
@@ -79,6 +85,17 @@ static int ncc_join(mis_ctx* ctx, NccWs* w)
     return MIS_OK;
 }
 
+// end of a call that built the tables (side stream joined): calls that reuse them on another stream wait for this point
+static int ncc_mark_built(mis_ctx* ctx, NccWs* w)
+{
+    if (!w->building) return MIS_OK;
+    w->building = false;
+    if (!w->ev_built) MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_built, hipEventDisableTiming));
+    MIS_HIP(ctx, hipEventRecord(w->ev_built, ctx->stream));
+    w->built_stream = ctx->stream;
+    return MIS_OK;
+}
+
 void mis_ncc_release(mis_ctx* ctx)
 {
     NccWs* w = ctx->ncc;
@@ -90,6 +107,7 @@ void mis_ncc_release(mis_ctx* ctx)
         (void)hipEventDestroy(w->ev_fork); (void)hipEventDestroy(w->ev_tables); (void)hipEventDestroy(w->ev_join);
         (void)hipStreamDestroy(w->side);
     }
+    if (w->ev_built) (void)hipEventDestroy(w->ev_built);
     delete w;
     ctx->ncc = nullptr;
 }
@@ -1099,8 +1117,11 @@ static int ncc_prepare(mis_ctx* ctx, int window, bool use_side)
         w->cap_px = npx;
         w->pair_serial = 0;
     }
-    if (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H)
+    if (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H) {
+        if (w->built_stream != ctx->stream && w->ev_built) MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, w->ev_built, 0));
         return MIS_OK;
+    }
+    w->building = true;
     w->pitch = pitch; w->rows = H;
     dim3 block(256);
     dim3 sgrid((pitch + 255) / 256, (H + NCC_STATS_BAND - 1) / NCC_STATS_BAND);
@@ -1257,7 +1278,12 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     a.row1 = (row0 + nrows < H - r) ? row0 + nrows : H - r;
     a.out_pitch = W;
     a.nstrips = a.nbands = 0;
-    if (a.row0 >= a.row1) { mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx); return ncc_join(ctx, w); }
+    if (a.row0 >= a.row1) {
+        mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx);
+        rc = ncc_join(ctx, w);
+        const int rcb = ncc_mark_built(ctx, w);
+        return rc ? rc : rcb;
+    }
     const int nd = dmax - dmin + 1;
     const int total_chunks = (nd + 63) / 64;
     // Rows per workgroup: every band re-runs the column sums of the 2r rows above it, so taller bands
@@ -1289,6 +1315,8 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
         const int rcj = ncc_join(ctx, w);
         if (!rc) rc = rcj;
     }
+    const int rcb = ncc_mark_built(ctx, w);
+    if (!rc) rc = rcb;
     mis_prof_mark(ctx);
     return rc;
 }

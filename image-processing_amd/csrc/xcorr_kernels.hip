@@ -1182,7 +1182,9 @@ static int xcorr_run(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, i
     int nb = (int)((2048ull << 20) / per);
     if (nb < 1) nb = 1;
     if (nb > n) nb = n;
-    if (nb > 65535) nb = 65535;
+    // tiles ride in grid.z (limit 65535); the general-size kernels put both images of a tile there
+    const int zmax = p.general ? 32767 : 65535;
+    if (nb > zmax) nb = zmax;
     XcorrWs* ws = ctx->xc;
     rc = mis_reserve(ctx, &ws->buf, &ws->buf_bytes, per * nb); if (rc) return rc;
     rc = mis_reserve(ctx, &ws->meta, &ws->meta_bytes, (size_t)nb * 16 + 512); if (rc) return rc;

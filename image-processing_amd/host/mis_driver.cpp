@@ -21,7 +21,7 @@ namespace {
 
 struct Node {
     mis_rect b1, b2;
-    std::vector<uint16_t> path;   // child indices from the root: depth-first order == lexicographic order
+    std::vector<uint32_t> path;   // child indices from the root: depth-first order == lexicographic order
 };
 
 int pow2_floor(int v) { int r = 0; while (v >>= 1) r++; return 1 << r; }
@@ -36,10 +36,11 @@ int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_s
     if (!ctx || !n_leaves || (max_leaves > 0 && !leaves) || min_size < 1) return MIS_ERR_ARG;
     *n_leaves = 0;
     if (n_tiles) *n_tiles = 0;
+    try {      // the containers below may throw (std::bad_alloc); nothing may leave the C ABI
     const int src_width = image_width, src_height = image_height;       // image3.cpp:684-685
     std::vector<Node> level(1);
     level[0].b1 = level[0].b2 = mis_rect{ 0, 0, image_width, image_height };   // image3.cpp:1001-1006
-    struct Leaf { mis_leaf l; std::vector<uint16_t> path; };
+    struct Leaf { mis_leaf l; std::vector<uint32_t> path; };
     std::vector<Leaf> out;
     int tiles = 0;
 
@@ -90,7 +91,7 @@ int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_s
 
             if (overlap.width > 2 * min_size && overlap.height > 2 * min_size && max > 0.75) {   // :751
                 const int dim = pow2_floor(std::min(overlap.width, overlap.height)) / 2;          // :754-761
-                uint16_t child = 0;
+                uint32_t child = 0;
                 for (int j = 0; j < overlap.height; j += dim) {                                  // :764-774
                     const int jj = j + dim > overlap.height ? overlap.height - dim : j;
                     for (int ii0 = 0; ii0 < overlap.width; ii0 += dim) {
@@ -123,26 +124,41 @@ int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_s
     if (n_tiles) *n_tiles = tiles;
     for (int i = 0; i < (int)out.size() && i < max_leaves; i++) leaves[i] = out[i].l;
     return MIS_OK;
+    } catch (...) {
+        return MIS_ERR_STATE;
+    }
 }
 
 // XYZ text output of image3.cpp:842-849: "%f %f %f " + one "%f " per band + newline.
 // bands: n x n_bands values sampled at (u1,v1) of each leaf (image3.cpp:838-841), may be NULL
 // when n_bands == 0.  append != 0 keeps an existing file (the reference writes as it goes).
-int mis_write_xyz(const char* path, const float* xyz, int n, const float* bands, int n_bands, int append)
+int mis_write_xyz_ex(const char* path, const float* xyz, int n, const float* bands, int n_bands, int flags)
 {
     if (!path || n < 0 || (n > 0 && !xyz) || n_bands < 0 || (n_bands > 0 && !bands)) return MIS_ERR_ARG;
-    FILE* f = fopen(path, append ? "a" : "w");
+    FILE* f = fopen(path, (flags & MIS_XYZ_APPEND) ? "a" : "w");
     if (!f) return MIS_ERR_STATE;
-    for (int i = 0; i < n; i++) {
-        std::string b;
-        for (int k = 0; k < n_bands; k++) {
-            char tmp[64];
-            snprintf(tmp, sizeof tmp, "%f ", bands[(size_t)i * n_bands + k]);
-            b += tmp;
+    try {
+        for (int i = 0; i < n; i++) {
+            std::string b;
+            for (int k = 0; k < n_bands; k++) {
+                char tmp[64];
+                snprintf(tmp, sizeof tmp, "%f ", bands[(size_t)i * n_bands + k]);
+                b += tmp;
+            }
+            // image3.cpp:830-846: the reference's buffer holds 10*n_bands bytes including the terminator
+            if ((flags & MIS_XYZ_REF_TRUNCATE) && n_bands > 0 && b.size() > (size_t)(10 * n_bands - 1)) b.resize(10 * n_bands - 1);
+            fprintf(f, "%f %f %f %s\n", xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], b.c_str());
         }
-        fprintf(f, "%f %f %f %s\n", xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], b.c_str());
+    } catch (...) {
+        fclose(f);
+        return MIS_ERR_STATE;
     }
     return fclose(f) == 0 ? MIS_OK : MIS_ERR_STATE;
+}
+
+int mis_write_xyz(const char* path, const float* xyz, int n, const float* bands, int n_bands, int append)
+{
+    return mis_write_xyz_ex(path, xyz, n, bands, n_bands, append ? MIS_XYZ_APPEND : 0);
 }
 
 // The three bands the reference writes into its "dispersion" GeoTIFF for every leaf

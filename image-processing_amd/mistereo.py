@@ -47,13 +47,13 @@ class MisError(RuntimeError):
 
 EXPORTS = [
     "mis_create", "mis_destroy", "mis_last_error", "mis_set_stream", "mis_synchronize",
-    "mis_upload_pair", "mis_bind_pair_device",
+    "mis_upload_pair", "mis_bind_pair_device", "mis_invalidate_pair",
     "mis_ncc_dense", "mis_ncc_dense_device", "mis_ncc_dense_rows_device",
     "mis_xcorr_tiles", "mis_xcorr_tiles_device", "mis_xcorr_tile_surfaces",
     "mis_fft2d_forward", "mis_xcorr_surface_u8",
     "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
     "mis_triangulate_disparity_noalloc",
-    "mis_disparity_map", "mis_write_xyz", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
+    "mis_disparity_map", "mis_write_xyz", "mis_write_xyz_ex", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
     "mis_set_extra_bands_device", "mis_upload_extra_bands", "mis_masked_peak",
     "mis_profile_enable", "mis_profile_read", "mis_version",
 ]
@@ -98,6 +98,8 @@ def load_library():
         lib.mis_triangulate_device.argtypes = [vp, vp, vp, vp, i32, vp]
         lib.mis_disparity_map.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp]
         lib.mis_write_xyz.argtypes = [C.c_char_p, vp, i32, vp, i32, i32]
+        lib.mis_write_xyz_ex.argtypes = [C.c_char_p, vp, i32, vp, i32, i32]
+        lib.mis_invalidate_pair.argtypes = [vp]
         lib.mis_rasterize_leaves.argtypes = [vp, i32, i32, i32, vp]
         lib.mis_profile_enable.argtypes = [vp, i32]
         lib.mis_profile_read.argtypes = [vp, vp, vp, vp, vp]
@@ -135,16 +137,20 @@ def make_camera(A, R, T):
     return cam
 
 
-def write_xyz(path, xyz, bands=None, append=False):
-    """XYZ text file in the reference's format (image3.cpp:842-849)."""
+XYZ_APPEND, XYZ_REF_TRUNCATE = 1, 2
+
+
+def write_xyz(path, xyz, bands=None, append=False, ref_truncate=False):
+    """XYZ text file in the reference's format (image3.cpp:842-849).  ref_truncate: cut the band text
+    of a line after 10*n_bands-1 characters as the reference's fixed buffer does (image3.cpp:830-846)."""
     lib = load_library()
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
     nb = 0
     if bands is not None:
         bands = np.ascontiguousarray(bands, np.float32).reshape(xyz.shape[0], -1)
         nb = bands.shape[1]
-    rc = lib.mis_write_xyz(os.fsencode(path), _np_ptr(xyz), xyz.shape[0], _np_ptr(bands) if nb else None, nb,
-                           1 if append else 0)
+    rc = lib.mis_write_xyz_ex(os.fsencode(path), _np_ptr(xyz), xyz.shape[0], _np_ptr(bands) if nb else None, nb,
+                              (XYZ_APPEND if append else 0) | (XYZ_REF_TRUNCATE if ref_truncate else 0))
     if rc != 0:
         raise MisError(rc, "mis_write_xyz failed for %s" % path)
 
@@ -268,6 +274,10 @@ class Context:
         self.shape = (h, w)
         self._keep = (t1, t2)
 
+    def invalidate_pair(self):
+        """The bound rasters' pixels changed in place: cached tables are rebuilt by the next call."""
+        self._check(self._lib.mis_invalidate_pair(self._h))
+
     # ---- dense NCC ----
     def ncc_dense(self, window, dmin, dmax, want_idisp=True, want_peak2=False):
         h, w = self.shape
@@ -370,6 +380,8 @@ class Context:
         leaves = (Leaf * max_leaves)()
         n, nt = C.c_int(0), C.c_int(0)
         self._check(self._lib.mis_disparity_map(self._h, w, h, min_size, leaves, max_leaves, C.byref(n), C.byref(nt)))
+        if n.value > max_leaves:                    # same answer in a buffer that holds them all
+            return self.disparity_map(min_size, n.value)
         recs = [(l.bbox1.minx, l.bbox1.miny, l.bbox1.width, l.bbox1.height, l.total_dx, l.total_dy,
                  l.u1, l.v1, l.u2, l.v2, l.peak) for l in leaves[:min(n.value, max_leaves)]]
         return recs, nt.value

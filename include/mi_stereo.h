@@ -68,9 +68,21 @@ int mis_synchronize(mis_ctx* ctx);
  * (image3.cpp:325-328, 979-980): the pair is copied to HBM once. */
 int mis_upload_pair(mis_ctx* ctx, const void* img1, const void* img2, int dtype,
                     int width, int height, size_t row_stride_bytes);
-/* Same, for rasters already in device memory (not copied; must stay valid while bound). */
+/* Same, for rasters already in device memory (not copied; must stay valid while bound).
+ * The dense-NCC entry points keep tables derived from the pixels (window statistics, packed copies)
+ * from one call to the next and rebuild them only when a pair is bound: a caller that writes new
+ * pixels into buffers that stay bound must rebind them or call mis_invalidate_pair before the next
+ * call, or that call answers for the old pixels.  Writes must be ordered before the next call on
+ * the context's stream by the caller.
+ * Both rasters have the same size and type.  (The reference only warns when the two datasets
+ * differ in size, image3.cpp:995-998, and then clips against the second one's extent,
+ * image3.cpp:684-685, 705-706: this library requires equal sizes; pad the smaller raster.) */
 int mis_bind_pair_device(mis_ctx* ctx, const void* d_img1, const void* d_img2, int dtype,
                          int width, int height, size_t row_stride_bytes);
+/* Declares that the pixels of the bound rasters have changed (same buffers, same geometry): every
+ * cached table is rebuilt by the next call that needs it.  No counterpart in the reference, which
+ * re-reads its rasters from the datasets inside every findOffset call (image3.cpp:325-328). */
+int mis_invalidate_pair(mis_ctx* ctx);
 
 /* ---- dense windowed NCC ------------------------------------------------------------------
  * The dense per-pixel mode the reference leaves disabled (image3.cpp:775-811) and lists as a
@@ -99,7 +111,11 @@ int mis_ncc_dense_rows_device(mis_ctx* ctx, int window, int dmin, int dmax, int 
  * Gaussian is subtracted and the first maximum of the difference gives (dx,dy).
  * tile_w, tile_h: any size up to 8192 (powers of two up to 16384).  Powers of two in 16..8192
  * run entirely in LDS-resident radix-2 transforms; other sizes (the reference's first level is
- * the whole raster) go through chirp-z row transforms and are slower per pixel. */
+ * the whole raster) go through chirp-z row transforms and are slower per pixel.
+ * A box that reaches past the raster is zero-filled pixel by pixel where it leaves it.  This is a
+ * deliberate choice, not the reference's behaviour (GDAL's RasterIO refuses such a window as a
+ * whole and image3.cpp:325 ignores the error: the buffer stays zero and findOffset returns -1);
+ * calcDisparityMap never produces such boxes (image3.cpp:702-740), only direct callers can. */
 int mis_xcorr_tiles(mis_ctx* ctx, const mis_rect* r1, const mis_rect* r2, int n,
                     int tile_w, int tile_h, mis_offset* out);
 int mis_xcorr_tiles_device(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, int n,
@@ -190,6 +206,14 @@ int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_s
 /* XYZ text file of image3.cpp:842-849: "%f %f %f " then one "%f " per band, newline; the format
  * xyz2pcd/xyzrgb2pcd.cpp:49 and xyz2geojson (its .rb scripts) read.  bands: n x n_bands samples (nullable). */
 int mis_write_xyz(const char* path, const float* xyz, int n, const float* bands, int n_bands, int append);
+/* Same with flags.  MIS_XYZ_REF_TRUNCATE reproduces the reference byte for byte: it formats the band
+ * values into a buffer of 10*n_bands bytes (image3.cpp:830-846), so the band text of a line is cut
+ * after 10*n_bands-1 characters: "%f " of any value >= 100 needs 11, digits of the last band(s)
+ * are lost and a fourth 16-bit band disappears.  Without the flag every band is written in full
+ * (what xyz2pcd/xyzrgb2pcd.cpp:49 can always parse); mis_write_xyz is that form. */
+#define MIS_XYZ_APPEND 1
+#define MIS_XYZ_REF_TRUNCATE 2
+int mis_write_xyz_ex(const char* path, const float* xyz, int n, const float* bands, int n_bands, int flags);
 
 /* The three Float32 bands of the reference's disparity GeoTIFF (image3.cpp:853-860, 872-893):
  * sqrtf(tx*tx+ty*ty), tx, ty, each leaf stretched over its bbox1; out = 3 planes of

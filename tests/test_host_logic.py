@@ -39,6 +39,28 @@ def test_write_xyz_format(tmp_path):
     assert open(p).read().split("\n")[0] == "1.500000 -2.250000 3.000000 "
 
 
+def test_write_xyz_reference_truncation(tmp_path):
+    """The reference formats the band values into 10*n_bands bytes (image3.cpp:830-846): the band text
+    of a line is cut after 10*n_bands-1 characters.  ref_truncate reproduces that byte for byte; the
+    default writes every band in full."""
+    xyz = np.array([[1.0, 2.0, 3.0]], np.float32)
+    p = os.path.join(tmp_path, "t.xyz")
+    # one band >= 100: 11 characters wanted, 9 kept
+    mistereo.write_xyz(p, xyz, np.array([[123.0]], np.float32), ref_truncate=True)
+    assert open(p).read() == "1.000000 2.000000 3.000000 123.00000\n"
+    # three 8-bit bands >= 100: 33 wanted, 29 kept
+    mistereo.write_xyz(p, xyz, np.array([[200.0, 150.0, 100.0]], np.float32), ref_truncate=True)
+    assert open(p).read() == "1.000000 2.000000 3.000000 200.000000 150.000000 100.000\n"
+    # four 16-bit bands: 13 characters each, the fourth band disappears (39 = 10*4-1 kept)
+    mistereo.write_xyz(p, xyz, np.array([[12345.0, 23456.0, 34567.0, 45678.0]], np.float32), ref_truncate=True)
+    assert open(p).read() == "1.000000 2.000000 3.000000 12345.000000 23456.000000 34567.000000 \n"
+    # values below 10 fit: 9 characters per band, nothing is cut
+    mistereo.write_xyz(p, xyz, np.array([[1.0, 2.5, 9.0]], np.float32), ref_truncate=True)
+    assert open(p).read() == "1.000000 2.000000 3.000000 1.000000 2.500000 9.000000 \n"
+    mistereo.write_xyz(p, xyz, np.array([[12345.0, 23456.0, 34567.0, 45678.0]], np.float32))
+    assert open(p).read() == "1.000000 2.000000 3.000000 12345.000000 23456.000000 34567.000000 45678.000000 \n"
+
+
 def test_rasterize_leaves():
     leaves = [(0, 0, 4, 4, 3, 4, 0, 0, 0, 0, 0.9), (2, 2, 4, 4, -1, 0, 0, 0, 0, 0, 0.8)]
     ras = mistereo.rasterize_leaves(leaves, 8, 8, fill=-9.0)

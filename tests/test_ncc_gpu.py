@@ -197,3 +197,82 @@ def test_back_to_back_calls_on_a_caller_stream():
             assert torch.equal(got[rep][0], want[rep % 2][0]) and torch.equal(got[rep][1], want[rep % 2][1])
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_pixels_rewritten_in_bound_buffers(dtype):
+    """Tables derived from the pixels are cached per bound pair: a caller that writes a new frame
+    into the same device buffers calls mis_invalidate_pair (or rebinds) and gets the new frame's
+    disparities; without it the previous frame's tables answer (the documented contract)."""
+    import torch
+    c = mistereo.Context(0)
+    try:
+        h, w = 80, 300
+        def frame(seed, shift):
+            left = _texture16(h, w, seed) if dtype == np.uint16 else synth.texture(h, w, seed)
+            return left, synth.shift_right_image(left, shift, fill_seed=seed + 1)
+        def cuda(a):
+            return torch.from_numpy(a.view(np.int16)).cuda().view(torch.uint16) if dtype == np.uint16 else torch.from_numpy(a).cuda()
+        l1, r1 = frame(1, 9)
+        l2, r2 = frame(2, -14)
+        tl, tr = cuda(l1), cuda(r1)
+        c.bind_pair_torch(tl, tr)
+        d = torch.empty((h, w), dtype=torch.float32, device="cuda"); p = torch.empty_like(d)
+        i16 = torch.empty((h, w), dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        c.ncc_dense_torch(11, -40, 40, d, p, i16)
+        c.synchronize()
+        first = i16.cpu().numpy().copy()
+        assert (first[20:60, 100:200] == 9).all()
+        tl.copy_(cuda(l2)); tr.copy_(cuda(r2))            # new pixels, same buffers
+        torch.cuda.synchronize()
+        c.ncc_dense_torch(11, -40, 40, d, p, i16)
+        c.synchronize()
+        assert np.array_equal(i16.cpu().numpy(), first)    # not invalidated: the cached tables still answer
+        c.invalidate_pair()
+        c.ncc_dense_torch(11, -40, 40, d, p, i16)
+        c.synchronize()
+        gpu = {"disp": d.cpu().numpy(), "peak": p.cpu().numpy(), "idisp": i16.cpu().numpy()}
+        ora = oracle.ncc_dense(l2, r2, 11, -40, 40, want_volume=True)
+        ora["flat"] = flat_mask(ora["volume"], ora["idisp"], -40)
+        compare_ncc(gpu, ora, volume=ora["volume"], dmin=-40)
+        # rebinding does the same
+        tl.copy_(cuda(l1)); tr.copy_(cuda(r1))
+        torch.cuda.synchronize()
+        c.bind_pair_torch(tl, tr)
+        c.ncc_dense_torch(11, -40, 40, d, p, i16)
+        c.synchronize()
+        assert np.array_equal(i16.cpu().numpy(), first)
+    finally:
+        c.close()
+
+
+def test_cached_tables_reused_from_another_stream():
+    """The first call after a bind builds the tables on the stream it runs on; a later call on a
+    different stream reuses them and is ordered behind that build by an event."""
+    import torch
+    c = mistereo.Context(0)
+    try:
+        h, w = 600, 1500
+        left = synth.texture(h, w, 5)
+        right = synth.shift_right_image(left, 21, fill_seed=6)
+        tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+        d1 = torch.empty((h, w), dtype=torch.float32, device="cuda"); p1 = torch.empty_like(d1)
+        d2 = torch.empty_like(d1); p2 = torch.empty_like(d1)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        c.bind_pair_torch(tl, tr)
+        c.set_stream(s1.cuda_stream)
+        c.ncc_dense_torch(21, -64, 64, d1, p1, row0=0, nrows=300)       # builds the tables on s1
+        c.set_stream(s2.cuda_stream)
+        c.ncc_dense_torch(21, -64, 64, d2, p2, row0=300, nrows=300)     # reuses them on s2, no host synchronisation between
+        torch.cuda.synchronize()
+        c.set_stream(None)
+        full_d = torch.empty_like(d1); full_p = torch.empty_like(d1)
+        c.bind_pair_torch(tl, tr)
+        c.ncc_dense_torch(21, -64, 64, full_d, full_p)
+        c.synchronize()
+        assert torch.equal(d1[:300], full_d[:300]) and torch.equal(d2[300:], full_d[300:])
+        assert torch.equal(p1[:300], full_p[:300]) and torch.equal(p2[300:], full_p[300:])
+    finally:
+        c.close()

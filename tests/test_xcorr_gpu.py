@@ -55,7 +55,9 @@ def test_batched_tiles_with_padding_and_offsets(ctx):
             ox, oy = (int(v) for v in rng.integers(-6, 7, 2))
             r2.append((min(max(i + ox, 0), 384), min(max(j + oy, 0), 384), 128, 128))
     r1.append((10, 20, 100, 90)); r2.append((14, 20, 100, 90))       # padded tile
-    r1.append((450, 470, 128, 128)); r2.append((450, 470, 128, 128))  # bbox runs off the raster
+    # bbox runs off the raster: zero-filled per pixel, the library's stated choice (parity unpinned:
+    # the reference's RasterIO refuses such a window and calcDisparityMap never produces one)
+    r1.append((450, 470, 128, 128)); r2.append((450, 470, 128, 128))
     got = ctx.find_offsets(r1, r2, 128, 128)
     for k, (a, b) in enumerate(zip(r1, r2)):
         ref = oracle.find_offset(img1, img2, a, b, 128, 128, precision=1)
@@ -102,13 +104,32 @@ def test_fft2d_forward_512(ctx):
     assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-5   # accuracy contract at 512^2
 
 
+def _check_surface_u8(got, img1, img2):
+    """Bytes against the oracle in the reference's own float32 arithmetic (precision 0) and in
+    float64 (precision 1).  floor(v * 255) turns a last-bit difference of v into a whole byte step
+    wherever v * 255 lies next to an integer, and float32 transforms of different butterfly order
+    differ in the last bits, so a small fraction of bytes is off by one; it is reported, and bounded."""
+    got = got.astype(np.int32)
+    frac = {}
+    for name, prec in (("float32 oracle", 0), ("float64 oracle", 1)):
+        want = oracle.xcorr_surface_u8(img1, img2, precision=prec).astype(np.int32)
+        d = np.abs(got - want)
+        assert d.max() <= 1, name
+        frac[name] = float((d > 0).mean())
+    # the two oracles differ from each other by about as much as the library differs from either
+    o32 = oracle.xcorr_surface_u8(img1, img2, precision=0).astype(np.int32)
+    o64 = oracle.xcorr_surface_u8(img1, img2, precision=1).astype(np.int32)
+    frac["float32 vs float64 oracle"] = float((o32 != o64).mean())
+    print("xcorr_surface_u8 %s: bytes off by one: %s" % (got.shape, ", ".join("%s %.4f %%" % (k, 100 * v) for k, v in frac.items())))
+    assert frac["float32 oracle"] <= 0.005 and frac["float64 oracle"] <= 0.005     # measured: 0.04 .. 0.10 %, the two oracles differ by 0.04 .. 0.08 %
+    return frac
+
+
 def test_xcorr_surface_u8(ctx):
     img1, img2 = _pair(128, 256, 30, -9, 17)
     ctx.upload_pair(img1, img2)
     got = ctx.xcorr_surface_u8().astype(np.int32)
-    want = oracle.xcorr_surface_u8(img1, img2, precision=1).astype(np.int32)
-    d = np.abs(got - want)
-    assert d.max() <= 1 and (d > 0).mean() <= 0.02     # floor() of float vs double surfaces
+    _check_surface_u8(got, img1, img2)
     py, px = np.unravel_index(np.argmax(got), got.shape)
     assert (px - 128, py - 64) == (30, -9)              # fft-shifted: offset relative to the centre
 
@@ -168,9 +189,25 @@ def test_xcorr_surface_u8_odd_size(ctx):
     img1, img2 = _pair(75, 101, 8, -6, 19)
     ctx.upload_pair(img1, img2)
     got = ctx.xcorr_surface_u8().astype(np.int32)
-    want = oracle.xcorr_surface_u8(img1, img2, precision=1).astype(np.int32)
-    d = np.abs(got - want)
-    assert d.max() <= 1 and (d > 0).mean() <= 0.02
+    _check_surface_u8(got, img1, img2)
+
+
+def test_more_small_tiles_than_one_grid_holds(ctx):
+    """45 000 tiles of 8 x 8 (the general-size path puts two images per tile into grid.z, whose limit
+    is 65535): batches are split, every tile still gets its own answer."""
+    img1, img2 = _pair(600, 2400, 1, 0, 77)
+    ctx.upload_pair(img1, img2)
+    xs, ys = np.meshgrid(np.arange(0, 2400, 8), np.arange(0, 600, 8))
+    rects = np.stack([xs.ravel(), ys.ravel(), np.full(xs.size, 8), np.full(xs.size, 8)], axis=1)
+    assert len(rects) == 22500
+    rects = np.concatenate([rects, rects])
+    got = ctx.find_offsets(rects, rects, 8, 8)
+    assert len(got) == 45000
+    assert np.array_equal(got[:22500], got[22500:])            # the repeated tiles repeat
+    for k in (0, 1234, 22499, 40000, 44999):
+        ref = oracle.find_offset(img1, img2, tuple(rects[k]), tuple(rects[k]), 8, 8, precision=1)
+        assert (got["dx"][k], got["dy"][k]) == (ref["dx"], ref["dy"])
+        assert abs(got["peak"][k] - ref["peak"]) <= 1e-4 * max(abs(ref["peak"]), 1e-3) + 1e-5
 
 
 @pytest.mark.parametrize("w,h", [(64, 64), (100, 60)])
@@ -245,7 +282,7 @@ def test_random_tile_sizes_boxes_and_types(ctx, seed):
     b1 = (int(rng.integers(0, 12)), int(rng.integers(0, 12)), int(rng.integers(w // 2, w + 1)), int(rng.integers(h // 2, h + 1)))
     b2 = (int(rng.integers(0, 12)), int(rng.integers(0, 12)), b1[2], b1[3])
     if seed % 6 == 0:
-        b1 = (w // 2, h // 2, w, h)                    # runs off the raster on the right / bottom
+        b1 = (w // 2, h // 2, w, h)                    # runs off the raster on the right / bottom (parity unpinned: see mi_stereo.h)
     ctx.upload_pair(img1, img2)
     peak, ox, oy = ctx.find_offset(b1, b2, w, h)
     ref = oracle.find_offset(img1, img2, b1, b2, w, h, precision=1, want_surface=True, want_dog=True)
