@@ -19,6 +19,7 @@ struct Ncc16Ws {
     size_t cap_px = 0;
     int pitch = 0, rows = 0, window = 0;
     uint64_t pair_serial = 0;
+    int built_lo = 0, built_hi = 0;             // raster rows whose tables exist (multiples of NCC16_STATS_BAND, or H)
     hipEvent_t ev_built = nullptr;              // end of the table build on built_stream (see ncc_kernels.hip)
     hipStream_t built_stream = nullptr;
 };
@@ -35,11 +36,11 @@ void mis_ncc16_release(mis_ctx* ctx)
 }
 
 __global__ __launch_bounds__(256) void ncc16_hsum_kernel(const uint16_t* __restrict__ img, size_t stride_px,
-                                                         int W, int H, int r, int pitch, int32_t* __restrict__ p32,
+                                                         int W, int H, int r, int pitch, int yfirst, int32_t* __restrict__ p32,
                                                          double* __restrict__ pd, int32_t* __restrict__ hs1, long long* __restrict__ hs2)
 {
     __shared__ int tile[256 + 2 * 16];
-    const int y = blockIdx.y, x0 = blockIdx.x * 256;
+    const int y = yfirst + blockIdx.y, x0 = blockIdx.x * 256;
     const uint16_t* row = img + (size_t)y * stride_px;
     for (int i = threadIdx.x; i < 256 + 2 * r; i += 256) {
         int x = x0 - r + i;
@@ -58,13 +59,13 @@ __global__ __launch_bounds__(256) void ncc16_hsum_kernel(const uint16_t* __restr
 
 #define NCC16_STATS_BAND 128
 template <bool LEFT>
-__global__ __launch_bounds__(256) void ncc16_stats_kernel(int W, int H, int r, int pitch,
+__global__ __launch_bounds__(256) void ncc16_stats_kernel(int W, int H, int r, int pitch, int band0,
                                                           const int32_t* __restrict__ hs1, const long long* __restrict__ hs2,
                                                           int32_t* __restrict__ osum, float* __restrict__ oinv, double* __restrict__ osumd)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= pitch) return;
-    const int y0 = blockIdx.y * NCC16_STATS_BAND, y1 = min(y0 + NCC16_STATS_BAND, H);
+    const int y0 = (band0 + blockIdx.y) * NCC16_STATS_BAND, y1 = min(y0 + NCC16_STATS_BAND, H);
     const long long N = (long long)(2 * r + 1) * (2 * r + 1);
     const bool colok = (x >= r && x < W - r);
     long long s1 = 0, s2 = 0;
@@ -410,7 +411,9 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
     oPeak[o] = s0 * il;
 }
 
-static int ncc16_prepare(mis_ctx* ctx, int window)
+// tables for raster rows [need_lo, need_hi) (the rows the requested output rows read); rows built by
+// earlier calls on the same pair are kept (see ncc_prepare in ncc_kernels.hip)
+static int ncc16_prepare(mis_ctx* ctx, int window, int need_lo, int need_hi)
 {
     Ncc16Ws* w = ctx->ncc16;
     if (!w) { w = new Ncc16Ws(); ctx->ncc16 = w; }
@@ -429,19 +432,41 @@ static int ncc16_prepare(mis_ctx* ctx, int window)
         w->cap_px = npx;
         w->pair_serial = 0;
     }
-    if (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H) {
+    need_lo = need_lo < 0 ? 0 : need_lo / NCC16_STATS_BAND * NCC16_STATS_BAND;
+    need_hi = (need_hi + NCC16_STATS_BAND - 1) / NCC16_STATS_BAND * NCC16_STATS_BAND;
+    if (need_hi > H) need_hi = H;
+    const bool same = (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H);
+    int lo[2], hi[2], nparts = 0;
+    if (same && need_lo >= w->built_lo && need_hi <= w->built_hi) {
         if (w->built_stream != ctx->stream && w->ev_built) MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, w->ev_built, 0));
         return MIS_OK;
     }
+    if (same && need_lo <= w->built_hi && need_hi >= w->built_lo) {
+        if (need_lo < w->built_lo) { lo[nparts] = need_lo; hi[nparts] = w->built_lo; nparts++; }
+        if (need_hi > w->built_hi) { lo[nparts] = w->built_hi; hi[nparts] = need_hi; nparts++; }
+        if (w->built_stream != ctx->stream && w->ev_built) MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, w->ev_built, 0));
+        w->built_lo = need_lo < w->built_lo ? need_lo : w->built_lo;
+        w->built_hi = need_hi > w->built_hi ? need_hi : w->built_hi;
+    } else {
+        lo[0] = need_lo; hi[0] = need_hi; nparts = 1;
+        w->built_lo = need_lo; w->built_hi = need_hi;
+    }
     w->pitch = pitch; w->rows = H;
-    dim3 grid((pitch + 255) / 256, H), block(256);
-    dim3 sgrid((pitch + 255) / 256, (H + NCC16_STATS_BAND - 1) / NCC16_STATS_BAND);
     hipStream_t s = ctx->stream;
     const size_t stride_px = ctx->stride / 2;
-    hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[0], stride_px, W, H, r, pitch, w->L32, w->Ld, w->hs1, w->hs2);
-    hipLaunchKernelGGL(ncc16_stats_kernel<true>, sgrid, block, 0, s, W, H, r, pitch, w->hs1, w->hs2, w->SL, w->iL, w->SLd);
-    hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[1], stride_px, W, H, r, pitch, w->R32, (double*)nullptr, w->hs1, w->hs2);
-    hipLaunchKernelGGL(ncc16_stats_kernel<false>, sgrid, block, 0, s, W, H, r, pitch, w->hs1, w->hs2, w->SR, w->iR, (double*)nullptr);
+    const dim3 block(256);
+    for (int k = 0; k < nparts; k++) {
+        // the statistics of a band need the horizontal sums of r rows above and below it (hs1 / hs2 are
+        // scratch shared by the two images, rewritten per image)
+        const int h0 = lo[k] - r > 0 ? lo[k] - r : 0, h1 = hi[k] + r < H ? hi[k] + r : H;
+        const dim3 grid((pitch + 255) / 256, h1 - h0);
+        const dim3 sgrid((pitch + 255) / 256, (hi[k] - lo[k] + NCC16_STATS_BAND - 1) / NCC16_STATS_BAND);
+        const int band0 = lo[k] / NCC16_STATS_BAND;
+        hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[0], stride_px, W, H, r, pitch, h0, w->L32, w->Ld, w->hs1, w->hs2);
+        hipLaunchKernelGGL(ncc16_stats_kernel<true>, sgrid, block, 0, s, W, H, r, pitch, band0, w->hs1, w->hs2, w->SL, w->iL, w->SLd);
+        hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[1], stride_px, W, H, r, pitch, h0, w->R32, (double*)nullptr, w->hs1, w->hs2);
+        hipLaunchKernelGGL(ncc16_stats_kernel<false>, sgrid, block, 0, s, W, H, r, pitch, band0, w->hs1, w->hs2, w->SR, w->iR, (double*)nullptr);
+    }
     MIS_HIP(ctx, hipGetLastError());
     if (!w->ev_built) MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_built, hipEventDisableTiming));
     MIS_HIP(ctx, hipEventRecord(w->ev_built, ctx->stream));
@@ -478,7 +503,8 @@ static int ncc16_launch(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, i
 // called by the dense-NCC entry points for 16-bit pairs; a: geometry already filled in
 int mis_ncc16_run(mis_ctx* ctx, int window, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
 {
-    int rc = ncc16_prepare(ctx, window);
+    const int r = window / 2;
+    int rc = ncc16_prepare(ctx, window, a.row0 - r, a.row1 + r);      // a.row0 / a.row1: output rows, clipped to [r, H-r)
     if (rc) return rc;
     a.pitch = ctx->ncc16->pitch;
     mis_prof_mark(ctx);

@@ -40,7 +40,8 @@ struct NccWs {
     size_t cap_px = 0;          // capacity in pixels (pitch*rows) of the arrays above
     int pitch = 0, rows = 0;
     uint64_t pair_serial = 0;   // tables valid for this pair ...
-    int window = 0;             // ... and this window
+    int window = 0;             // ... this window ...
+    int built_lo = 0, built_hi = 0;   // ... and these raster rows [built_lo, built_hi) (multiples of NCC_STATS_BAND, or H)
     // Second stream of the fast path: the small kernels nothing waits for until the refinement
     // (vertical packs, frame border, tail disparities) run beside the argmax kernel instead of in
     // front of it.  ev_fork orders the side stream behind the main one, ev_tables behind the tables,
@@ -123,7 +124,7 @@ void mis_ncc_release(mis_ctx* ctx)
 #define NCC_STATS_BAND 64
 template <typename T, bool LEFT>
 __global__ __launch_bounds__(256) void ncc_tables_kernel(const T* __restrict__ img, size_t stride_px,
-                                                         int W, int H, int r, int pitch,
+                                                         int W, int H, int r, int pitch, int band0,
                                                          uint32_t* __restrict__ pack,
                                                          float* __restrict__ o0,   // LEFT: negc   RIGHT: S_R
                                                          float* __restrict__ o1,   // LEFT: negg   RIGHT: iR
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void ncc_tables_kernel(const T* __restrict__ i
     __shared__ uint32_t ring[31][256];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * 256, x = x0 + tid;
-    const int y0 = blockIdx.y * NCC_STATS_BAND;
+    const int y0 = (band0 + blockIdx.y) * NCC_STATS_BAND;      // the launch covers bands band0 .. band0 + gridDim.y - 1
     const int y1 = min(y0 + NCC_STATS_BAND, H);
     const int Wn = 2 * r + 1;
     const long long N = (long long)Wn * Wn;
@@ -226,10 +227,10 @@ __global__ __launch_bounds__(256) void ncc_tables_kernel(const T* __restrict__ i
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void ncc_vpack_kernel(const T* __restrict__ img, size_t stride_px, int W, int H,
-                                                        int pitch, uint32_t* __restrict__ out)
+                                                        int pitch, int q0, uint32_t* __restrict__ out)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
-    const int q = blockIdx.y;
+    const int q = q0 + blockIdx.y;
     if (x >= pitch) return;
     uint32_t v = 0;
     if (x < W) {
@@ -1099,7 +1100,11 @@ __global__ __launch_bounds__(256) void ncc_border_kernel(float* disp, float* pea
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
-static int ncc_prepare(mis_ctx* ctx, int window, bool use_side)
+// Builds (or reuses) the per-pair tables for raster rows [need_lo, need_hi): the rows the correlation of
+// the requested output rows reads.  The tables of rows built by earlier calls on the same pair are kept,
+// so a frame computed strip by strip builds every band of rows once, and a rank that computes one strip
+// of a frame builds that strip's rows only.
+static int ncc_prepare(mis_ctx* ctx, int window, bool use_side, int need_lo, int need_hi)
 {
     NccWs* w = ctx->ncc;
     const int W = ctx->width, H = ctx->height, r = window / 2;
@@ -1117,14 +1122,29 @@ static int ncc_prepare(mis_ctx* ctx, int window, bool use_side)
         w->cap_px = npx;
         w->pair_serial = 0;
     }
-    if (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H) {
+    // whole bands of rows
+    need_lo = need_lo < 0 ? 0 : need_lo / NCC_STATS_BAND * NCC_STATS_BAND;
+    need_hi = (need_hi + NCC_STATS_BAND - 1) / NCC_STATS_BAND * NCC_STATS_BAND;
+    if (need_hi > H) need_hi = H;
+    const bool same = (w->pair_serial == ctx->pair_serial && w->window == window && w->pitch == pitch && w->rows == H);
+    int lo[2], hi[2], nparts = 0;                        // row ranges to build now
+    if (same && need_lo >= w->built_lo && need_hi <= w->built_hi) {
         if (w->built_stream != ctx->stream && w->ev_built) MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, w->ev_built, 0));
         return MIS_OK;
+    }
+    if (same && need_lo <= w->built_hi && need_hi >= w->built_lo) {     // touches what exists: build what is missing on either side
+        if (need_lo < w->built_lo) { lo[nparts] = need_lo; hi[nparts] = w->built_lo; nparts++; }
+        if (need_hi > w->built_hi) { lo[nparts] = w->built_hi; hi[nparts] = need_hi; nparts++; }
+        if (w->built_stream != ctx->stream && w->ev_built) MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, w->ev_built, 0));
+        w->built_lo = need_lo < w->built_lo ? need_lo : w->built_lo;
+        w->built_hi = need_hi > w->built_hi ? need_hi : w->built_hi;
+    } else {
+        lo[0] = need_lo; hi[0] = need_hi; nparts = 1;
+        w->built_lo = need_lo; w->built_hi = need_hi;
     }
     w->building = true;
     w->pitch = pitch; w->rows = H;
     dim3 block(256);
-    dim3 sgrid((pitch + 255) / 256, (H + NCC_STATS_BAND - 1) / NCC_STATS_BAND);
     hipStream_t s = ctx->stream, sv = ctx->stream;       // sv: side stream when there is one
     if (use_side) {
         int rc = ncc_fork(ctx, w);
@@ -1137,15 +1157,26 @@ static int ncc_prepare(mis_ctx* ctx, int window, bool use_side)
     const uint8_t* pr = (const uint8_t*)ctx->img[1];
     // the two table kernels run side by side (each alone leaves wave slots idle); the main stream
     // then waits for the right image's tables only, not for the vertical packs queued behind them
-    hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, false>), sgrid, block, 0, sv, pr, ctx->stride, W, H, r, pitch,
-                       w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
+    for (int k = 0; k < nparts; k++) {
+        const int band0 = lo[k] / NCC_STATS_BAND;
+        const dim3 sgrid((pitch + 255) / 256, (hi[k] - lo[k] + NCC_STATS_BAND - 1) / NCC_STATS_BAND);
+        hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, false>), sgrid, block, 0, sv, pr, ctx->stride, W, H, r, pitch, band0,
+                           w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
+    }
     if (use_side) MIS_HIP(ctx, hipEventRecord(w->ev_tables, w->side));
-    hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, true>), sgrid, block, 0, s, pl, ctx->stride, W, H, r, pitch,
-                       w->Lpack, w->negc, w->negg, w->iL);
+    for (int k = 0; k < nparts; k++) {
+        const int band0 = lo[k] / NCC_STATS_BAND;
+        const dim3 sgrid((pitch + 255) / 256, (hi[k] - lo[k] + NCC_STATS_BAND - 1) / NCC_STATS_BAND);
+        hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, true>), sgrid, block, 0, s, pl, ctx->stride, W, H, r, pitch, band0,
+                           w->Lpack, w->negc, w->negg, w->iL);
+    }
     if (use_side) MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, w->ev_tables, 0));
-    const dim3 vgrid((pitch + 255) / 256, (H + 3) / 4);
-    hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, vgrid, block, 0, sv, pl, ctx->stride, W, H, pitch, w->VL);
-    hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, vgrid, block, 0, sv, pr, ctx->stride, W, H, pitch, w->VR);
+    for (int k = 0; k < nparts; k++) {
+        const int q0 = lo[k] / 4, q1 = (hi[k] + 3) / 4;  // bands are multiples of 4 rows, except the last one of the raster
+        const dim3 vgrid((pitch + 255) / 256, q1 - q0);
+        hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, vgrid, block, 0, sv, pl, ctx->stride, W, H, pitch, q0, w->VL);
+        hipLaunchKernelGGL(ncc_vpack_kernel<uint8_t>, vgrid, block, 0, sv, pr, ctx->stride, W, H, pitch, q0, w->VR);
+    }
     MIS_HIP(ctx, hipGetLastError());
     w->pair_serial = ctx->pair_serial;
     w->window = window;
@@ -1267,7 +1298,13 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     if (ctx->dtype != MIS_U8)
         return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: 8-bit and 16-bit rasters only");
     if (!ctx->ncc) ctx->ncc = new NccWs();
-    int rc = ncc_prepare(ctx, window, fast);
+    int rc = MIS_OK;
+    {
+        // rows the kernels of this call read: packed pairs and vertical packs of the window rows of every
+        // output row, statistics of the output rows themselves
+        const int o0 = row0 > r ? row0 : r, o1 = (row0 + nrows < H - r) ? row0 + nrows : H - r;
+        if (o0 < o1) rc = ncc_prepare(ctx, window, fast, o0 - r, o1 + r);
+    }
     if (rc) { (void)ncc_join(ctx, ctx->ncc); return rc; }
 
     NccWs* w = ctx->ncc;

@@ -102,3 +102,26 @@ def test_config2_tiles_recover_their_offsets(ctx):
         ref = oracle.find_offset(left, right, rects[k], rects[k], tile, tile, precision=1)
         assert (dx, dy) == (ref["dx"], ref["dy"])
         assert abs(peak - ref["peak"]) <= 1e-4 * max(abs(ref["peak"]), 1e-3) + 1e-5
+
+
+def test_a_strip_builds_only_its_rows_of_tables(ctx, full):
+    """Row strip of 1024 rows of the 8192-row frame (what one of 8 ranks computes): the table kernels
+    cover the strip's rows plus the window halo, rounded to 64-row bands, so their device time is about
+    an eighth of the full frame's (measured with the library's own HIP events)."""
+    import torch
+    left, right, out = full
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    d = torch.empty((SIZE, SIZE), dtype=torch.float32, device="cuda"); p = torch.empty_like(d)
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    times = {}
+    for name, (row0, n) in (("warm", (0, SIZE)), ("full", (0, SIZE)), ("strip", (3072, 1024))):
+        ctx.bind_pair_torch(tl, tr)
+        ctx.profile_read()
+        ctx.ncc_dense_torch(WIN, -D, D, d, p, row0=row0, nrows=n)
+        tables_ms, main_ms, refine_ms, calls = ctx.profile_read()
+        times[name] = (tables_ms, main_ms)
+    ctx.profile(False)
+    assert np.array_equal(d[3072:4096].cpu().numpy().view(np.uint32), out["disp"][3072:4096].view(np.uint32))
+    assert times["strip"][0] <= 0.3 * times["full"][0], times
+    assert times["strip"][1] <= 0.2 * times["full"][1], times

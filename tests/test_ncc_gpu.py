@@ -276,3 +276,33 @@ def test_cached_tables_reused_from_another_stream():
         assert torch.equal(p1[:300], full_p[:300]) and torch.equal(p2[300:], full_p[300:])
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_strips_in_any_order_build_only_their_rows(ctx, dtype):
+    """The per-pair tables are built for the rows a call reads and kept for later calls: strips taken
+    bottom-up, with a gap, overlapping and repeated give the full frame's bits."""
+    import torch
+    h, w = 700, 400
+    left = _texture16(h, w, 31) if dtype == np.uint16 else synth.texture(h, w, 31)
+    right = synth.shift_right_image(left, 7, fill_seed=32)
+    if dtype == np.uint16:
+        tl = torch.from_numpy(left.view(np.int16)).cuda().view(torch.uint16)
+        tr = torch.from_numpy(right.view(np.int16)).cuda().view(torch.uint16)
+    else:
+        tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    ctx.bind_pair_torch(tl, tr)
+    full_d = torch.empty((h, w), dtype=torch.float32, device="cuda"); full_p = torch.empty_like(full_d)
+    ctx.ncc_dense_torch(9, -20, 45, full_d, full_p)
+    ctx.synchronize()
+    ctx.bind_pair_torch(tl, tr)                          # drops the tables
+    d = torch.full_like(full_d, 777.0); p = torch.full_like(full_d, 777.0)
+    order = [(600, 100), (0, 130), (300, 150), (130, 170), (440, 170), (250, 120), (0, 700)]
+    for row0, n in order[:-1]:
+        ctx.ncc_dense_torch(9, -20, 45, d, p, row0=row0, nrows=n)
+    ctx.synchronize()
+    covered = torch.zeros(h, dtype=torch.bool)
+    for row0, n in order[:-1]:
+        covered[row0:row0 + n] = True
+    assert covered.all()
+    assert torch.equal(d, full_d) and torch.equal(p, full_p)
