@@ -3,15 +3,23 @@
 
 One step = one full pass of the dense windowed-NCC hot path over one synthetic stereo pair that
 is already resident in HBM: frame-border fill, window-statistics tables, main correlation kernel
-(argmax + subpixel).  Workload at N=1: BASELINE config[1] -- 8192x8192 8-bit pair, 21x21 window,
-+-256 px search.  With N>1 every rank processes a pair of its own (weak scaling: frames are
-independent units) and the disparity/peak rasters are gathered to rank 0 over RCCL while the next
-step computes.
+(argmax), refinement (exact scores, subpixel).  Workload at N=1: BASELINE config[1] -- 8192x8192
+8-bit pair, 21x21 window, +-256 px search.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+With N>1 (one process per GPU, launched by torch.distributed.run) there are two partitions:
+  --partition frames  (default)  every rank processes a pair of its own (weak scaling: frames are
+                                 independent units, BASELINE config[3]'s batch of pairs);
+  --partition strips             ONE pair for the whole job, sharded by row strips with the window
+                                 halo (strong scaling): a rank holds and uploads only its strip plus
+                                 halo rows and computes its rows.
+In both, disparity and peak rasters are gathered to rank 0 over RCCL while the next step computes.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--partition frames|strips]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  At N=1 the line also carries, outside the headline value, the
+FFT tile correlation (path_f) and the 16-bit dense NCC (ncc16) with their own rooflines and CPU
+baselines (--extras off skips them).
 """
 import argparse
 import json
@@ -22,11 +30,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, "image-processing_amd"), os.path.join(ROOT, "oracle")]
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+VECTOR_PEAK_TFLOPS = 157.3     # MI355X vector fp32 peak (packed fma)
 ALG_BYTES_PER_PX_U8 = 10.0     # left + right pixel read once, disparity f32 + peak f32 written
+ALG_BYTES_PER_PX_U16 = 12.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -34,15 +44,19 @@ def parse():
     ap.add_argument("--size", type=int, default=8192, help="frame is size x size pixels")
     ap.add_argument("--window", type=int, default=21)
     ap.add_argument("--disp", type=int, default=256, help="search is +-disp pixels")
+    ap.add_argument("--partition", choices=["frames", "strips"], default="frames",
+                    help="with N>1: a pair per rank (weak scaling) or row strips of one pair (strong scaling)")
     ap.add_argument("--gather", choices=["on", "off"], default="on",
                     help="with N>1: gather disparity/peak rasters to rank 0 (overlapped)")
     ap.add_argument("--cpu-rows", type=int, default=8192,
                     help="rows of the frame the CPU oracle is timed on (0: skip the CPU baseline)")
-    return ap.parse_args()
+    ap.add_argument("--extras", choices=["on", "off"], default="on",
+                    help="at N=1: also measure the FFT tile correlation and the 16-bit dense NCC")
+    return ap.parse_args(argv)
 
 
 def load_traffic_note(kernel_name, field="bytes"):
-    """HBM bytes per launch (or another field) of the dominant kernel from a committed rocprofv3 --pmc run."""
+    """HBM bytes per launch (or another field) of a kernel from a committed rocprofv3 --pmc run."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
@@ -55,8 +69,9 @@ def load_traffic_note(kernel_name, field="bytes"):
 def issue_floor(W, H, window, nd, kernel_s):
     """Time the argmax kernel's own instruction mix needs at full vector-issue rate, for the 21x21
     window: 509 ns of SIMD time per strip row (32 columns x 64 disparities; per-instruction prices
-    measured with tools/ubench/valu_rates on this part: dot2c 94, DPP maxima 93, sliding sums 89,
-    packed fmas 86, keys 58, rest 90), 1024 SIMDs, 256- or 128-row bands with 2r warm-up rows."""
+    measured with tools/ubench/valu_rates on this part, kept in profiles/: dot2c 94, DPP maxima 93,
+    sliding sums 89, packed fmas 86, keys 58, rest 90), 1024 SIMDs, 256- or 128-row bands with 2r
+    warm-up rows."""
     if window != 21:
         return None
     r = window // 2
@@ -72,7 +87,8 @@ def issue_floor(W, H, window, nd, kernel_s):
 
 
 class GatherPipeline:
-    """Double-buffered gather of per-rank result rasters to rank 0, overlapped with the next step.
+    """Double-buffered gather of per-rank result rasters to rank 0, overlapped with the next step
+    (frames partition: every rank contributes a whole raster).
 
     submit(b) starts an asynchronous torch.distributed.gather of buffer b; reuse(b) must be called
     before buffer b is written again and waits for that gather.  Works with any backend (RCCL on
@@ -102,6 +118,243 @@ class GatherPipeline:
             self.reuse(b)
 
 
+class StripJob:
+    """One pair sharded by row strips (strips partition).  Rank r owns output rows [r0, r0+n) and
+    holds rows [lo, lo+nin) of the frame (its strip plus the window halo) as a raster of its own;
+    rank 0 owns the full result rasters and receives every other rank's rows straight into them
+    (grouped point-to-point transfers, see partition.StripGather), double buffered so that the
+    transfers of one step overlap the next step's correlation.
+
+    compute(disp, peak, local_row0, nrows) fills rows [local_row0, local_row0+nrows) of the given
+    rasters (addressed as the rank's own raster; on rank 0 that addressing equals the frame's);
+    before_compute / after_compute order the device streams around it (None on the CPU)."""
+
+    def __init__(self, rank, world, H, W, window, device, compute, before_compute=None, after_compute=None,
+                 nbuf=2, gather=True):
+        import torch
+        import partition
+        self.rank, self.world, self.nbuf = rank, world, nbuf
+        self.strips = partition.row_strips(H, world)
+        self.r0, self.n = self.strips[rank]
+        self.lo, self.nin = partition.strip_input_rows(self.r0, self.n, H, window)
+        self.local_row0 = self.r0 - self.lo
+        rows_out = H if rank == 0 else max(self.nin, 1)
+        self.out = [[torch.empty((rows_out, W), dtype=torch.float32, device=device) for _ in range(2)]
+                    for _ in range(nbuf)]
+        self.gathers = [partition.StripGather(self.strips, rank, world, full=self.out[b] if rank == 0 else None)
+                        for b in range(nbuf)] if (gather and world > 1) else None
+        self.compute, self.before_compute, self.after_compute = compute, before_compute, after_compute
+
+    def step(self, i):
+        b = i % self.nbuf
+        if self.gathers:
+            self.gathers[b].wait()                  # the buffer's previous transfers have drained
+        if self.before_compute:
+            self.before_compute()
+        if self.n > 0:
+            self.compute(self.out[b][0], self.out[b][1], self.local_row0, self.n)
+        if self.after_compute:
+            self.after_compute()
+        if self.gathers:
+            self.gathers[b].submit([t[self.local_row0:self.local_row0 + self.n] for t in self.out[b]])
+
+    def drain(self):
+        if self.gathers:
+            for g in self.gathers:
+                g.wait()
+
+    def result(self, i):
+        """Rank 0: the full (disparity, peak) rasters of step i."""
+        return self.out[i % self.nbuf]
+
+
+def synth_pair(H, W, D, seed):
+    """Synthetic pair of BASELINE config[1]'s kind: texture, piecewise-constant disparity, +-2 DN noise."""
+    import numpy as np
+    import synth
+    left = synth.texture(H, W, seed)
+    dl, dh = (-min(200, D - 56), min(200, D - 56)) if D > 60 else (-D // 2, D // 2)
+    dmap = synth.planar_disparity(H, W, dl, dh, 64, seed + 1)
+    right = synth.shift_right_image(left, dmap, fill_seed=seed + 1000)
+    noise = (synth.splitmix64(seed + 2, H * W) % np.uint64(5)).astype(np.int16).reshape(H, W) - 2
+    right = np.clip(right.astype(np.int16) + noise, 0, 255).astype(np.uint8)
+    return left, right
+
+
+def bench_path_f(ctx, stream, dev, left_h, steps=10):
+    """BASELINE config[2]: FFT tile correlation (findOffset, image3.cpp:346-517) of 512 x 512 tiles over
+    the frame, a different offset in [-100,100]^2 per tile, one batched call per step; plus config[0]'s
+    recursion (calcDisparityMap, image3.cpp:676-865) on a 2048 x 2048 pair."""
+    import numpy as np
+    import torch
+    import oracle
+    import synth
+    from concurrent.futures import ThreadPoolExecutor
+    size, tile = left_h.shape[0], 512
+    nt = size // tile
+    n = nt * nt
+    rnd = synth.splitmix64(0xC0FFEE + 4, 2 * n).reshape(n, 2)
+    offs = (rnd % np.uint64(201)).astype(np.int64) - 100
+    right = np.empty_like(left_h)
+    pad = np.pad(left_h, 128, mode="reflect")
+    rects = np.empty((n, 4), np.int32)
+    for k in range(n):
+        j, i = divmod(k, nt)
+        dx, dy = int(offs[k, 0]), int(offs[k, 1])
+        y0, x0 = j * tile + 128 + dy, i * tile + 128 + dx
+        right[j * tile:(j + 1) * tile, i * tile:(i + 1) * tile] = pad[y0:y0 + tile, x0:x0 + tile]
+        rects[k] = (i * tile, j * tile, tile, tile)
+    del pad
+    tl, tr = torch.from_numpy(left_h).to(dev), torch.from_numpy(right).to(dev)
+    d_rects = torch.from_numpy(rects).to(dev)
+    d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        ctx.bind_pair_torch(tl, tr)
+        for _ in range(2):
+            ctx.find_offsets_torch(d_rects, d_rects, tile, tile, d_out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            ctx.find_offsets_torch(d_rects, d_rects, tile, tile, d_out)
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    got = d_out.cpu().numpy()
+    recovered = int(((got[:, 0] == offs[:, 0]) & (got[:, 1] == offs[:, 1])).sum())
+    N = tile * tile
+    flop_tile = 3 * 5 * N * np.log2(N) + 2 * 2 * 151 * N + 16 * N      # three transforms, two Gaussian passes, pointwise
+    alg_tile = 2 * N * 1 + 16
+    res = {
+        "workload": "BASELINE config[2]: %d tiles of %dx%d over a %dx%d 8-bit pair, offsets in [-100,100]^2" % (n, tile, tile, size, size),
+        "ms_per_batch": round(ms, 4), "tiles_per_s": round(n / ms * 1e3, 1), "gpx_per_s": round(n * N / ms / 1e6, 3),
+        "offsets_recovered": "%d/%d" % (recovered, n),
+        "roofline": {"flop_per_tile": float(flop_tile), "achieved_tflops": round(n * flop_tile / ms / 1e9, 3),
+                     "vector_peak_tflops": VECTOR_PEAK_TFLOPS, "vector_frac": round(n * flop_tile / ms / 1e9 / VECTOR_PEAK_TFLOPS, 4),
+                     "algorithmic_bytes_per_tile": alg_tile, "hbm_achieved_gbs": round(n * alg_tile / ms / 1e6, 2),
+                     "hbm_frac": round(n * alg_tile / ms / 1e6 / HBM_PEAK_GBS, 5),
+                     "traffic": load_traffic_note("xcorr_batch")},
+    }
+    # CPU: the oracle's findOffset.  All cores: tiles side by side, one thread each.  Reference-shaped: what
+    # image3.cpp's structure gives -- one tile after another, allocation and set-up inside every call, one thread.
+    cores = oracle.num_threads()
+    ncpu = min(n, 2 * cores)
+
+    def one(k):
+        oracle.set_num_threads(1)
+        r = oracle.find_offset(left_h, right, tuple(rects[k]), tuple(rects[k]), tile, tile, precision=0)
+        return (r["dx"], r["dy"])
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        cpu_offs = list(ex.map(one, range(ncpu)))
+    tc = time.perf_counter() - t0
+    res["cpu_baseline"] = {"value": round(ncpu / tc, 2), "unit": "tiles/s", "cores": cores, "kind": "port",
+                           "sample": "%d of the same tiles, CPU oracle findOffset (C, float32), one tile per thread, %.2f s" % (ncpu, tc),
+                           "offsets_equal_gpu": bool(all(tuple(int(v) for v in got[k, :2]) == cpu_offs[k] for k in range(ncpu)))}
+    oracle.set_num_threads(1)
+    t0 = time.perf_counter()
+    for k in range(3):
+        oracle.find_offset(left_h, right, tuple(rects[k]), tuple(rects[k]), tile, tile, precision=0)
+    ts = time.perf_counter() - t0
+    oracle.set_num_threads(cores)
+    res["cpu_reference_shaped"] = {"value": round(3 / ts, 3), "unit": "tiles/s", "cores": 1, "kind": "port",
+                                   "sample": "3 tiles one after another, buffers and set-up inside every call (the structure of image3.cpp:357-372), %.2f s" % ts}
+    del tl, tr
+    # config[0]: the coarse-to-fine recursion on a 2048 x 2048 pair with a known horizontal shift
+    l2, r2, _ = synth.config_pair(1)
+    ctx.set_stream(None)
+    ctx.upload_pair(l2, r2)
+    ctx.disparity_map(min_size=32)
+    t0 = time.perf_counter()
+    leaves, calls = ctx.disparity_map(min_size=32)
+    tg = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oleaves, ocalls = oracle.disparity_map(l2, r2, min_size=32)
+    to = time.perf_counter() - t0
+    res["recursion_2048"] = {"workload": "BASELINE config[0] pair (2048x2048, shift 17): calcDisparityMap, min size 32, host rasters in, leaves out",
+                             "findoffset_calls": calls, "leaves": len(leaves), "ms": round(tg * 1e3, 2),
+                             "cpu_oracle_s": round(to, 2), "cpu_cores_blur_only": cores,
+                             "leaves_equal_oracle": bool(calls == ocalls and [l[:10] for l in leaves] == [l[:10] for l in oleaves])}
+    ctx.set_stream(stream.cuda_stream)
+    return res
+
+
+def bench_ncc16(ctx, stream, dev, steps=3):
+    """BASELINE config[4]'s kernel work on a band: 16384 x 1024, 16-bit, 31x31 window, +-512 search
+    (1025 disparities), subpixel, every matched pixel triangulated."""
+    import numpy as np
+    import torch
+    import mistereo
+    import oracle
+    import synth
+    W, H, win, D = 16384, 1024, 31, 512
+    nd = 2 * D + 1
+    left = synth.texture(H, W, 0xC0FFEE + 5, np.uint16)
+    rng = np.random.default_rng(5)
+    left = np.clip(left.astype(np.int64) + rng.integers(-120, 121, left.shape), 0, 65535).astype(np.uint16)
+    right = synth.shift_right_image_subpixel(left, 37.25)
+    tl = torch.from_numpy(left.view(np.int16)).to(dev).view(torch.uint16)
+    tr = torch.from_numpy(right.view(np.int16)).to(dev).view(torch.uint16)
+    disp = torch.empty((H, W), dtype=torch.float32, device=dev)
+    peak = torch.empty_like(disp)
+    idisp = torch.empty((H, W), dtype=torch.int16, device=dev)
+    xyz = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    A = [[10000.0, 0.0, W / 2.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
+    cam1 = mistereo.make_camera(A, np.eye(3), [0.0, 0.0, -3000.0])
+    cam2 = mistereo.make_camera(A, np.eye(3), [-900.0, 0.0, -3000.0])
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        ctx.bind_pair_torch(tl, tr)
+        ctx.ncc_dense_torch(win, -D, D, disp, peak, idisp)
+        ctx.triangulate_disparity_torch(cam1, cam2, disp, peak, 0.75, xyz, count=False)
+        stream.synchronize()
+        ctx.profile(True)
+        ctx.profile_read()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record(stream)
+        for _ in range(steps):
+            ctx.bind_pair_torch(tl, tr)                     # every step rebuilds the tables
+            ctx.ncc_dense_torch(win, -D, D, disp, peak)
+        e[1].record(stream)
+        for _ in range(steps):
+            ctx.triangulate_disparity_torch(cam1, cam2, disp, peak, 0.75, xyz, count=False)
+        e[2].record(stream)
+        matched = int(ctx.triangulate_disparity_torch(cam1, cam2, disp, peak, 0.75, xyz))
+    stream.synchronize()
+    tables_ms, main_ms, refine_ms, calls = ctx.profile_read()
+    ctx.profile(False)
+    ms, tri_ms = e[0].elapsed_time(e[1]) / steps, e[1].elapsed_time(e[2]) / steps
+    kernel_ms = main_ms / max(calls, 1)
+    alg = ALG_BYTES_PER_PX_U16 * H * W
+    res = {
+        "workload": "BASELINE config[4] band: %dx%d 16-bit, %dx%d window, +-%d px (%d disparities), subpixel + XYZ" % (W, H, win, win, D, nd),
+        "ms_per_step": round(ms, 3), "gpx_disp_per_s": round(H * W * nd / ms / 1e6, 2),
+        "triangulation_ms": round(tri_ms, 3), "matched_points": matched,
+        "matched_points_per_s": round(matched / (ms + tri_ms) * 1e3, 1),
+        "roofline": {"bound": "hbm", "kernel": "ncc16_argmax_kernel", "kernel_ms": round(kernel_ms, 3),
+                     "tables_ms": round(tables_ms / max(calls, 1), 3), "refine_ms": round(refine_ms / max(calls, 1), 3),
+                     "algorithmic_bytes": alg, "achieved": round(alg / kernel_ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / kernel_ms / 1e6 / HBM_PEAK_GBS, 5), "kernel_gpx_disp_per_s": round(H * W * nd / kernel_ms / 1e6, 2),
+                     "traffic": load_traffic_note("ncc16_argmax_kernel")},
+    }
+    r = win // 2
+    rows = min(32 * oracle.num_threads(), H - 2 * r)     # the oracle's threads each take 32-row strips
+    cl, cr = np.ascontiguousarray(left[: rows + 2 * r]), np.ascontiguousarray(right[: rows + 2 * r])
+    t0 = time.perf_counter()
+    ora = oracle.ncc_dense(cl, cr, win, -D, D)
+    tc = time.perf_counter() - t0
+    # GPU rows of the crop in the crop's own coordinates (its first and last r rows are border rows)
+    full = {"disp": np.full((rows + 2 * r, W), -32768, np.float32), "peak": np.zeros((rows + 2 * r, W), np.float32),
+            "idisp": np.full((rows + 2 * r, W), -32768, np.int16)}
+    for k, t in (("disp", disp), ("peak", peak), ("idisp", idisp)):
+        full[k][r: r + rows] = t[r: r + rows].cpu().numpy()
+    rep = oracle.parity_report(full["disp"], full["peak"], ora, cl, cr, win, -D, D, gpu_idisp=full["idisp"])
+    res["cpu_baseline"] = {"value": round((rows + 2 * r) * W * nd / tc / 1e9, 4), "unit": "Gpx*disp/s", "cores": oracle.num_threads(),
+                           "kind": "port", "sample": "first %d rows of the same band, CPU oracle (C, OpenMP, int64 sums), %.1f s" % (rows + 2 * r, tc),
+                           "parity": rep}
+    return res
+
+
 def main():
     args = parse()
     import numpy as np
@@ -109,7 +362,7 @@ def main():
     import torch.distributed as dist
 
     import mistereo
-    import synth
+    import partition
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -131,51 +384,82 @@ def main():
     H = W = args.size
     D = args.disp
     nd = 2 * D + 1
-    # synthetic pair of BASELINE config[1]'s kind, a different seed per rank
-    seed = 0xC0FFEE + 2 + 7919 * rank
-    left_h = synth.texture(H, W, seed)
-    dmap = synth.planar_disparity(H, W, -min(200, D - 56) if D > 60 else -D // 2, min(200, D - 56) if D > 60 else D // 2,
-                                  64, seed + 1)
-    right_h = synth.shift_right_image(left_h, dmap, fill_seed=seed + 1000)
-    noise = (synth.splitmix64(seed + 2, H * W) % np.uint64(5)).astype(np.int16).reshape(H, W) - 2
-    right_h = np.clip(right_h.astype(np.int16) + noise, 0, 255).astype(np.uint8)
-    del noise, dmap
-
-    left = torch.from_numpy(left_h).to(dev)
-    right = torch.from_numpy(right_h).to(dev)
-    nbuf = 2
-    disp = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    peak = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    do_gather = world > 1 and args.gather == "on"
-    packed = [torch.empty((2, H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
-    pipe = GatherPipeline(rank, world, packed) if do_gather else None
+    strips_mode = args.partition == "strips" and world > 1
+    # frames: a different pair per rank; strips: the same pair on every rank (each keeps its strip only)
+    seed = 0xC0FFEE + 2 + (0 if strips_mode else 7919 * rank)
+    left_h, right_h = synth_pair(H, W, D, seed)
 
     ctx = mistereo.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
-    def step(i):
-        b = i % nbuf
-        if pipe:
-            pipe.reuse(b)              # the buffer's previous gather has drained (a wait on torch's current stream) ...
-            stream.wait_stream(torch.cuda.current_stream())   # ... and the library's stream must honour it too
-        with torch.cuda.stream(stream):
-            # re-binding invalidates the context's per-pair tables: every step redoes all the work
-            ctx.bind_pair_torch(left, right)
-            if do_gather:
-                ctx.ncc_dense_torch(args.window, -D, D, packed[b][0], packed[b][1])
-            else:
-                ctx.ncc_dense_torch(args.window, -D, D, disp[b], peak[b])
-        if do_gather:
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            torch.cuda.current_stream().wait_event(ev)
-            pipe.submit(b)
+    do_gather = world > 1 and args.gather == "on"
+    nbuf = 2
 
-    def drain():
-        if pipe:
-            pipe.drain()
-        stream.synchronize()
-        torch.cuda.synchronize()
+    def lib_waits_for_torch():
+        stream.wait_stream(torch.cuda.current_stream())
+
+    def torch_waits_for_lib():
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        torch.cuda.current_stream().wait_event(ev)
+
+    if strips_mode:
+        r0, n = partition.row_strips(H, world)[rank]
+        lo, nin = partition.strip_input_rows(r0, n, H, args.window)
+        left = torch.from_numpy(np.ascontiguousarray(left_h[lo:lo + nin])).to(dev)      # the strip and its halo rows only
+        right = torch.from_numpy(np.ascontiguousarray(right_h[lo:lo + nin])).to(dev)
+        if rank != 0:
+            del left_h, right_h
+
+        def compute(disp_t, peak_t, local_row0, nrows):
+            with torch.cuda.stream(stream):
+                ctx.bind_pair_torch(left, right)             # re-binding drops the per-pair tables: every step redoes all the work
+                ctx.ncc_dense_torch(args.window, -D, D, disp_t, peak_t, row0=local_row0, nrows=nrows)
+
+        job = StripJob(rank, world, H, W, args.window, dev, compute, lib_waits_for_torch, torch_waits_for_lib,
+                       nbuf=nbuf, gather=do_gather)
+        step = job.step
+
+        def drain():
+            job.drain()
+            stream.synchronize()
+            torch.cuda.synchronize()
+
+        def last_result(steps):
+            return job.result(max(steps - 1, 0))
+    else:
+        left = torch.from_numpy(left_h).to(dev)
+        right = torch.from_numpy(right_h).to(dev)
+        disp = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        peak = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        packed = [torch.empty((2, H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
+        pipe = GatherPipeline(rank, world, packed) if do_gather else None
+
+        def step(i):
+            b = i % nbuf
+            if pipe:
+                pipe.reuse(b)              # the buffer's previous gather has drained (a wait on torch's current stream) ...
+                lib_waits_for_torch()      # ... and the library's stream must honour it too
+            with torch.cuda.stream(stream):
+                # re-binding invalidates the context's per-pair tables: every step redoes all the work
+                ctx.bind_pair_torch(left, right)
+                if do_gather:
+                    ctx.ncc_dense_torch(args.window, -D, D, packed[b][0], packed[b][1])
+                else:
+                    ctx.ncc_dense_torch(args.window, -D, D, disp[b], peak[b])
+            if do_gather:
+                torch_waits_for_lib()
+                pipe.submit(b)
+
+        def drain():
+            if pipe:
+                pipe.drain()
+            stream.synchronize()
+            torch.cuda.synchronize()
+
+        def last_result(steps):
+            b = max(steps - 1, 0) % nbuf
+            return (packed[b][0], packed[b][1]) if do_gather else (disp[b], peak[b])
 
     for i in range(args.warmup):
         step(i)
@@ -201,55 +485,64 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # matched points (peak >= 0.75, the reference's accept threshold image3.cpp:751), outside the timed region
-    last = (args.steps - 1) % nbuf if args.steps > 0 else 0
-    pk = packed[last][1] if do_gather else peak[last]
-    dp = packed[last][0] if do_gather else disp[last]
-    # every matched pixel triangulated to XYZ (calculateXYZ, image3.cpp:148-264) with two synthetic nadir
-    # cameras (f = 10000 px, height 3000 m, baseline 900 m, R = I), timed on its own
-    A = [[10000.0, 0.0, W / 2.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
-    cam1 = mistereo.make_camera(A, np.eye(3), [0.0, 0.0, -3000.0])
-    cam2 = mistereo.make_camera(A, np.eye(3), [-900.0, 0.0, -3000.0])
-    xyz = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-    with torch.cuda.stream(stream):
-        ctx.triangulate_disparity_torch(cam1, cam2, dp, pk, 0.75, xyz)      # warm-up
-        stream.synchronize()
-        t_tri = time.perf_counter()
-        matched = int(ctx.triangulate_disparity_torch(cam1, cam2, dp, pk, 0.75, xyz))   # reading the count synchronises
-        t_tri = time.perf_counter() - t_tri
-    del xyz
-
     result = None
     if rank == 0:
-        work = float(H) * W * nd * world            # px*disp per step, all ranks
+        dp, pk = last_result(args.steps)
+        # every matched pixel (peak >= 0.75, the reference's accept threshold image3.cpp:751) triangulated to XYZ
+        # (calculateXYZ, image3.cpp:148-264) with two synthetic nadir cameras (f = 10000 px, height 3000 m,
+        # baseline 900 m, R = I), timed on its own, outside the timed region
+        A = [[10000.0, 0.0, W / 2.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
+        cam1 = mistereo.make_camera(A, np.eye(3), [0.0, 0.0, -3000.0])
+        cam2 = mistereo.make_camera(A, np.eye(3), [-900.0, 0.0, -3000.0])
+        xyz = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        n_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            # the raster size is passed in: in the strips partition rank 0's bound raster is its strip only
+            ctx.triangulate_disparity_noalloc_torch(cam1, cam2, dp, pk, 0.75, xyz, n_dev)      # warm-up
+            stream.synchronize()
+            t_tri = time.perf_counter()
+            ctx.triangulate_disparity_noalloc_torch(cam1, cam2, dp, pk, 0.75, xyz, n_dev)
+            stream.synchronize()
+            t_tri = time.perf_counter() - t_tri
+        matched = int(n_dev.item())
+        del xyz
+
+        frames_per_step = 1 if strips_mode else world
+        work = float(H) * W * nd * frames_per_step          # px*disp per step, all ranks
         value = work * args.steps / dt / 1e9
+        # the dominant kernel's launch covers this rank's rows
+        rows_rank0 = partition.row_strips(H, world)[0][1] if strips_mode else H
         kernel_s = (main_ms / max(calls, 1)) / 1e3
-        alg_bytes = ALG_BYTES_PER_PX_U8 * H * W
+        alg_bytes = ALG_BYTES_PER_PX_U8 * rows_rank0 * W
         achieved = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
         kname = "ncc_argmax_kernel"
+        wl = ("BASELINE config[1]" if (W, args.window, D) == (8192, 21, 256) else
+              "BASELINE config[3] frame size (one of its 16 pairs)" if (W, args.window, D) == (16384, 21, 256) else "non-baseline size")
         result = {
             "metric": "NCC throughput", "value": round(value, 3), "unit": "Gpx*disp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strips_mode else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d 8-bit synthetic aerial pair, %dx%d NCC window, +-%d px search (%d disparities) per GPU"
-                                   % ("BASELINE config[1]" if (W, args.window, D) == (8192, 21, 256) else
-                                      "BASELINE config[3] frame size (one of its 16 pairs)" if (W, args.window, D) == (16384, 21, 256) else
-                                      "non-baseline size", W, H, args.window, args.window, D, nd),
+            "config": {"workload": "%s: %dx%d 8-bit synthetic aerial pair, %dx%d NCC window, +-%d px search (%d disparities)%s"
+                                   % (wl, W, H, args.window, args.window, D, nd,
+                                      ", ONE pair sharded by row strips with halo" if strips_mode else " per GPU"),
                        "window": args.window, "dmin": -D, "dmax": D,
+                       "partition": "strips" if strips_mode else "frames",
                        "gather_to_rank0": bool(do_gather)},
-            "matched_points_per_s": round(matched * world / (dt / max(args.steps, 1) + t_tri), 1),
+            "matched_points_per_s": round(matched * (1 if strips_mode else world) / (dt / max(args.steps, 1) + t_tri), 1),
             "matched_points": {"per_frame": matched, "peak_threshold": 0.75, "triangulation_ms": round(t_tri * 1e3, 3),
                                "note": "correspondences with peak >= 0.75 triangulated to XYZ; rate = points / (correlation step + triangulation)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic_note(kname),
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/ (not measured in this run)",
                          "kernel": kname, "kernel_ms": round(kernel_s * 1e3, 4),
                          "tables_ms": round(pre_ms / max(calls, 1), 4),
                          "refine_ms": round(refine_ms / max(calls, 1), 4),
                          "algorithmic_bytes": alg_bytes,
                          "valu_busy_frac_pmc": load_traffic_note(kname, "valu_busy"),
-                         "issue_floor": issue_floor(W, H, args.window, nd, kernel_s),
+                         "issue_floor": issue_floor(W, rows_rank0, args.window, nd, kernel_s) if not strips_mode else None,
                          "note": "sliding-window correlation: compulsory HBM traffic is 10 B/px whatever the search "
                                  "range, the kernel is bound by vector ALU / LDS issue, not by HBM"},
         }
@@ -263,21 +556,28 @@ def main():
             ora = oracle.ncc_dense(crop_l, crop_r, args.window, -D, D)
             tc = time.perf_counter() - t1
             cpu_work = float(rows + 2 * r) * W * nd
-            # cross-check the GPU rows against the oracle while we have both
-            gi = disp[last][r: r + rows].round().to(torch.int32).cpu().numpy() if not do_gather else None
-            agree = None
-            if gi is not None:
-                oi = ora["idisp"][r: r + rows].astype(np.int32)
-                valid = oi != -32768
-                gd = disp[last][r: r + rows].cpu().numpy()
-                agree = float((np.abs(gd - ora["disp"][r: r + rows])[valid] <= 0.01).mean())
+            # cross-check the GPU rows against the oracle while we have both: one more (untimed) call that also
+            # writes the integer disparity
+            idisp = torch.empty((H, W), dtype=torch.int16, device=dev)
+            with torch.cuda.stream(stream):
+                ctx.ncc_dense_torch(args.window, -D, D, dp, pk, idisp)
+            stream.synchronize()
+            hh = rows + 2 * r
+            gd, gp, gi = dp[:hh].cpu().numpy(), pk[:hh].cpu().numpy(), idisp[:hh].cpu().numpy()
+            if hh < H:      # the crop's last r rows are border rows of the crop only
+                gd[-r:] = -32768.0; gp[-r:] = 0.0; gi[-r:] = -32768
+            rep = oracle.parity_report(gd, gp, ora, crop_l, crop_r, args.window, -D, D, gpu_idisp=gi)
             result["cpu_baseline"] = {
                 "value": round(cpu_work / tc / 1e9, 4), "unit": "Gpx*disp/s", "cores": oracle.num_threads(),
                 "kind": "port",
                 "sample": "first %d rows of the same pair (%.2f Gpx*disp), CPU oracle (C, OpenMP), %.1f s"
                           % (rows + 2 * r, cpu_work / 1e9, tc),
-                "gpu_vs_oracle_disp_within_0.01px": agree,
+                "parity": rep,
             }
+            del ora, gd, gp, gi, idisp
+        if world == 1 and args.extras == "on":
+            result["path_f"] = bench_path_f(ctx, stream, dev, left_h)
+            result["ncc16"] = bench_ncc16(ctx, stream, dev)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

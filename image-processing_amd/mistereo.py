@@ -316,6 +316,13 @@ class Context:
         res = np.frombuffer(out, dtype=[("dx", "<i4"), ("dy", "<i4"), ("peak", "<f4"), ("dog_peak", "<f4")])
         return res.copy()
 
+    def find_offsets_torch(self, rects1, rects2, tile_w, tile_h, out):
+        """Batched findOffset on device memory: rects1 / rects2 int32 CUDA tensors [n, 4], out an int32
+        CUDA tensor [n, 4] that receives (dx, dy, peak bits, DoG peak bits); only enqueues."""
+        n = rects1.shape[0]
+        self._check(self._lib.mis_xcorr_tiles_device(self._h, _dev_ptr(rects1), _dev_ptr(rects2), n, tile_w, tile_h,
+                                                     _dev_ptr(out)))
+
     def find_offset(self, bbox1, bbox2, width, height):
         """findOffset(bbox1, bbox2, width, height, &ox, &oy) -> (peak, ox, oy)."""
         r = self.find_offsets([bbox1], [bbox2], width, height)[0]

@@ -37,6 +37,16 @@ int orc_num_threads(void)
 #endif
 }
 
+/* threads used by the OpenMP regions started from the calling thread (1: a serial run) */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n < 1 ? 1 : n);
+#else
+    (void)n;
+#endif
+}
+
 static inline int64_t px_at(const void* img, int dtype, size_t stride, int x, int y)
 {
     const unsigned char* row = (const unsigned char*)img + (size_t)y * stride;
@@ -60,6 +70,15 @@ double orc_ncc_score(const void* L, const void* R, int dtype, int width, int hei
     int64_t num = N * slr - sl * sr, vl = N * sll - sl * sl, vr = N * srr - sr * sr;
     if (vl <= 0 || vr <= 0) return 0.0;
     return (double)num / sqrt((double)vl * (double)vr);
+}
+
+/* orc_ncc_score for n (x, y, d) triples */
+void orc_ncc_scores(const void* L, const void* R, int dtype, int width, int height, size_t stride,
+                    int window, int n, const int* xs, const int* ys, const int* ds, double* out)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++)
+        out[i] = orc_ncc_score(L, R, dtype, width, height, stride, window, xs[i], ys[i], ds[i]);
 }
 
 /* summed-area table with one guard row/column: sat[(y+1)*(w+1) + (x+1)] = sum over [0..x]x[0..y] */

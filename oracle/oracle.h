@@ -97,6 +97,9 @@ int orc_disparity_map(const void* img1, const void* img2, int dtype, int width, 
                       orc_leaf* leaves, int max_leaves, int* n_find_offset_calls);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
+void orc_ncc_scores(const void* left, const void* right, int dtype, int width, int height, size_t stride_bytes,
+                    int window, int n, const int* xs, const int* ys, const int* ds, double* out);
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,81 @@ def ncc_score(left, right, window, x, y, d):
                                C.c_size_t(left.strides[0]), window, int(x), int(y), int(d))
 
 
+def ncc_scores(left, right, window, xs, ys, ds):
+    """float64 NCC of the window at (x, y) against the window at (x - d, y), for arrays of triples."""
+    left = np.ascontiguousarray(left)
+    right = np.ascontiguousarray(right)
+    h, w = left.shape
+    xs = np.ascontiguousarray(xs, np.int32); ys = np.ascontiguousarray(ys, np.int32); ds = np.ascontiguousarray(ds, np.int32)
+    out = np.empty(xs.shape[0], np.float64)
+    lib().orc_ncc_scores(_ptr(left), _ptr(right), _dtype_code(left), w, h, C.c_size_t(left.strides[0]), window,
+                         xs.shape[0], _ptr(xs), _ptr(ys), _ptr(ds), _ptr(out))
+    return out
+
+
+def parity_report(gpu_disp, gpu_peak, ora, left, right, window, dmin, dmax, gpu_idisp=None, near_tie=2e-5,
+                  peak_rtol=1e-4, subpx_atol=0.01, flat_eps=1e-4):
+    """The three parity bars of the dense NCC, each on its own, for a GPU result (disp, peak rasters)
+    against this oracle's result `ora` on the same rasters:
+      argmax_agree                  fraction of valid pixels with the same integer disparity
+      argmax_diffs_all_near_tie     every differing pixel's two disparities score within `near_tie` of
+                                    each other (float64 scores of both, recomputed for those pixels only)
+      peak_within_1e-4              fraction of agreeing pixels whose peaks agree to 1e-4 relative
+      subpx_within_0.01_on_agreeing fraction of agreeing pixels whose subpixel disparities agree to 0.01 px,
+                                    with NO pixel excluded; the outliers are then classified: a parabola
+                                    whose denominator |s- - 2 s0 + s+| is below `flat_eps` is ill-conditioned
+                                    (float32 noise of the three scores moves its vertex)."""
+    oi = ora["idisp"].astype(np.int32)
+    if gpu_idisp is not None:
+        gi = gpu_idisp.astype(np.int32)
+    else:
+        # the integer disparity is the subpixel value rounded (|delta| <= 0.5); a value at .5 is resolved
+        # with the oracle's integer when that is one of the two candidates
+        gi = np.where(gpu_disp == np.float32(INVALID_DISP), INVALID_DISP, np.rint(gpu_disp)).astype(np.int32)
+        lo, hi = np.floor(gpu_disp), np.ceil(gpu_disp)
+        half = (oi != INVALID_DISP) & (np.abs(gpu_disp - lo - 0.5) < 1e-6)
+        gi = np.where(half & ((lo == oi) | (hi == oi)), oi, gi)
+    valid = oi != INVALID_DISP
+    nvalid = int(valid.sum())
+    rep = {"valid_pixels": nvalid, "validity_masks_equal": bool(np.array_equal(gi == INVALID_DISP, ~valid))}
+    if nvalid == 0:
+        return rep
+    same = valid & (gi == oi)
+    diff = valid & ~same
+    rep["argmax_agree"] = float(same.sum() / nvalid)
+    rep["argmax_diffs"] = int(diff.sum())
+    if diff.any():
+        ys, xs = np.nonzero(diff)
+        sg = ncc_scores(left, right, window, xs, ys, gi[ys, xs])
+        so = ncc_scores(left, right, window, xs, ys, oi[ys, xs])
+        gap = np.abs(sg - so)
+        rep["argmax_diffs_all_near_tie"] = bool(np.all(gap <= near_tie))
+        rep["argmax_diffs_max_score_gap"] = float(np.nanmax(gap))
+    else:
+        rep["argmax_diffs_all_near_tie"] = True
+        rep["argmax_diffs_max_score_gap"] = 0.0
+    gp, op = gpu_peak[same], ora["peak"][same]
+    rep["peak_within_1e-4"] = float((np.abs(gp - op) <= peak_rtol * np.maximum(np.abs(op), 1e-3) + 2e-6).mean())
+    rep["peak_max_abs_diff"] = float(np.abs(gp - op).max())
+    bad = same & (np.abs(gpu_disp - ora["disp"]) > subpx_atol)
+    rep["subpx_within_0.01_on_agreeing"] = float(1.0 - bad.sum() / max(int(same.sum()), 1))
+    rep["subpx_outliers"] = int(bad.sum())
+    if bad.any():
+        ys, xs = np.nonzero(bad)
+        d0 = oi[ys, xs]
+        s0 = ncc_scores(left, right, window, xs, ys, d0)
+        sm = ncc_scores(left, right, window, xs, ys, d0 - 1)
+        sp = ncc_scores(left, right, window, xs, ys, d0 + 1)
+        den = np.abs(sm - 2 * s0 + sp)
+        rep["subpx_outliers_ill_conditioned"] = int((~(den > flat_eps)).sum())
+        rep["subpx_outliers_max_diff_well_conditioned"] = float(np.abs(gpu_disp - ora["disp"])[ys, xs][den > flat_eps].max()) \
+            if (den > flat_eps).any() else 0.0
+    else:
+        rep["subpx_outliers_ill_conditioned"] = 0
+        rep["subpx_outliers_max_diff_well_conditioned"] = 0.0
+    return rep
+
+
 def fft2d(data, sign, double=True):
     """In-place-style 2-D DFT of a complex array (unnormalised); returns a new array."""
     if double:
@@ -238,3 +313,8 @@ def disparity_map(img1, img2, min_size=32, precision=0, max_leaves=1 << 16):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    """OpenMP threads for oracle calls made from the calling thread (1: serial)."""
+    lib().orc_set_num_threads(int(n))

@@ -157,6 +157,64 @@ def test_bench_gather_pipeline_world2_gloo():
     assert q.get(timeout=5) is True
 
 
+def _strip_job_worker(rank, world, port, h, w, window, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r = window // 2
+        state = {"step": 0}
+        job_box = []
+
+        def compute(disp, peak, local_row0, nrows):
+            # stands for the library call: every output row gets a value made of its GLOBAL row index and
+            # the step, computed from the rank's own strip geometry as the real call would
+            job = job_box[0]
+            assert disp.shape[0] >= local_row0 + nrows
+            rows = torch.arange(job.r0, job.r0 + nrows, dtype=torch.float32)[:, None]
+            disp[local_row0:local_row0 + nrows] = rows * 10 + state["step"]
+            peak[local_row0:local_row0 + nrows] = -rows - 1000 * state["step"]
+
+        job = bench.StripJob(rank, world, h, w, window, "cpu", compute)
+        job_box.append(job)
+        # the rank holds its strip plus the window halo, clipped to the frame
+        assert job.lo == max(0, job.r0 - r) and job.lo + job.nin == min(h, job.r0 + job.n + r)
+        ok = True
+        for i in range(5):                           # the bench loop
+            state["step"] = i
+            job.step(i)
+        job.drain()
+        if rank == 0:
+            rows = torch.arange(h, dtype=torch.float32)[:, None].expand(h, w)
+            for i in (3, 4):                         # both buffers still hold their last step
+                d, p = job.result(i)
+                ok = ok and bool(torch.equal(d, rows * 10 + i)) and bool(torch.equal(p, -rows - 1000 * i))
+            q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 37), (3, 64)])
+def test_bench_strip_job_gloo(world, h):
+    """bench.py --partition strips with a stub in place of the library call: strip ownership, halo rows,
+    double buffering and the point-to-point gather into rank 0's full rasters (uneven strips)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_strip_job_worker, args=(r, world, port, h, 16, 7, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 OPENCV_YAML = """%YAML:1.0
 A: !!opencv-matrix
    rows: 3
