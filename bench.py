@@ -181,7 +181,7 @@ def synth_pair(H, W, D, seed):
     return left, right
 
 
-def bench_path_f(ctx, stream, dev, left_h, steps=10):
+def bench_path_f(ctx, stream, dev, left_h, steps=10, cpu=True):
     """BASELINE config[2]: FFT tile correlation (findOffset, image3.cpp:346-517) of 512 x 512 tiles over
     the frame, a different offset in [-100,100]^2 per tile, one batched call per step; plus config[0]'s
     recursion (calcDisparityMap, image3.cpp:676-865) on a 2048 x 2048 pair."""
@@ -235,6 +235,8 @@ def bench_path_f(ctx, stream, dev, left_h, steps=10):
                      "hbm_frac": round(n * alg_tile / ms / 1e6 / HBM_PEAK_GBS, 5),
                      "traffic": load_traffic_note("xcorr_batch")},
     }
+    if not cpu:
+        return res
     # CPU: the oracle's findOffset.  All cores: tiles side by side, one thread each.  Reference-shaped: what
     # image3.cpp's structure gives -- one tile after another, allocation and set-up inside every call, one thread.
     cores = oracle.num_threads()
@@ -279,7 +281,7 @@ def bench_path_f(ctx, stream, dev, left_h, steps=10):
     return res
 
 
-def bench_ncc16(ctx, stream, dev, steps=3):
+def bench_ncc16(ctx, stream, dev, steps=3, cpu=True):
     """BASELINE config[4]'s kernel work on a band: 16384 x 1024, 16-bit, 31x31 window, +-512 search
     (1025 disparities), subpixel, every matched pixel triangulated."""
     import numpy as np
@@ -337,6 +339,8 @@ def bench_ncc16(ctx, stream, dev, steps=3):
                      "frac": round(alg / kernel_ms / 1e6 / HBM_PEAK_GBS, 5), "kernel_gpx_disp_per_s": round(H * W * nd / kernel_ms / 1e6, 2),
                      "traffic": load_traffic_note("ncc16_argmax_kernel")},
     }
+    if not cpu:
+        return res
     r = win // 2
     rows = min(32 * oracle.num_threads(), H - 2 * r)     # the oracle's threads each take 32-row strips
     cl, cr = np.ascontiguousarray(left[: rows + 2 * r]), np.ascontiguousarray(right[: rows + 2 * r])
@@ -576,8 +580,8 @@ def main():
             }
             del ora, gd, gp, gi, idisp
         if world == 1 and args.extras == "on":
-            result["path_f"] = bench_path_f(ctx, stream, dev, left_h)
-            result["ncc16"] = bench_ncc16(ctx, stream, dev)
+            result["path_f"] = bench_path_f(ctx, stream, dev, left_h, cpu=args.cpu_rows > 0)
+            result["ncc16"] = bench_ncc16(ctx, stream, dev, cpu=args.cpu_rows > 0)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

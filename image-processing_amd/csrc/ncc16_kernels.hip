@@ -1,9 +1,15 @@
 // Dense windowed NCC for 16-bit rasters, gfx950: the same lane <-> disparity walk and batched
 // argmax as the 8-bit path (ncc_kernels.hip), with exact 64-bit integer sums instead of the
 // f16/f32 trick: a product of two 16-bit pixels needs 31 bits and a 31x31 window sum 41.
-//   column sums and window sums: binary64, updated with v_fma_f64 (full rate on CDNA3/4); every
-//   value is an integer below 2^53, so the arithmetic is exact
-//   num = N*S_LR - S_L*S_R exactly, score = float(num) * (1/sqrt(N var_L)) * (1/sqrt(N var_R))
+//   column sums: 64-bit integers updated with v_mad_i64_i32 (one instruction multiplies two 32-bit
+//   operands and adds the 64-bit accumulator: half the instructions of a convert + v_fma_f64 pair).
+//   The left operand is stored premultiplied by N = W*W, so the sums are N*S_LR directly.
+//   Every accumulator carries the bit pattern of the double 1.5*2^52 as an additive constant: read
+//   as a double it IS 1.5*2^52 + sum, exactly (|sum| < 2^51), so the difference of two accumulators
+//   in v_add_f64 is their exact integer difference and the window sum slides along the strip in
+//   binary64 without any conversion instruction.
+//   num = N*S_LR - S_L*S_R exactly (binary64, integers below 2^53),
+//   score = float(num) * (1/sqrt(N var_L)) * (1/sqrt(N var_R))
 // Pixels are shifted by 32768 into int16 range first.  Exact like the oracle.  Definition: see mi_stereo.h (dense windowed NCC).
 #include "ncc_shared.h"
 
@@ -13,7 +19,8 @@ struct Ncc16Ws {
     int32_t *L32 = nullptr, *R32 = nullptr;     // shifted rasters, pitch P
     int32_t *SL = nullptr, *SR = nullptr;       // window sums of the shifted pixels
     float *iL = nullptr, *iR = nullptr;         // 1/sqrt(N*sum sq - sum^2); iR NaN where the window does not fit
-    double *Ld = nullptr, *SLd = nullptr;       // left pixels and left window sums as binary64 (wave-uniform operands)
+    int32_t* NL = nullptr;                      // N * (left pixel - 32768): wave-uniform operand of the column sums
+    double* SLd = nullptr;                      // left window sums as binary64 (wave-uniform operand of the numerator)
     int32_t* hs1 = nullptr; long long* hs2 = nullptr;
     float* keys = nullptr; size_t keys_bytes = 0;
     size_t cap_px = 0;
@@ -28,7 +35,7 @@ void mis_ncc16_release(mis_ctx* ctx)
 {
     Ncc16Ws* w = ctx->ncc16;
     if (!w) return;
-    void* bufs[] = { w->L32, w->R32, w->SL, w->SR, w->iL, w->iR, w->hs1, w->hs2, w->keys, w->Ld, w->SLd };
+    void* bufs[] = { w->L32, w->R32, w->SL, w->SR, w->iL, w->iR, w->hs1, w->hs2, w->keys, w->NL, w->SLd };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (w->ev_built) (void)hipEventDestroy(w->ev_built);
     delete w;
@@ -37,7 +44,7 @@ void mis_ncc16_release(mis_ctx* ctx)
 
 __global__ __launch_bounds__(256) void ncc16_hsum_kernel(const uint16_t* __restrict__ img, size_t stride_px,
                                                          int W, int H, int r, int pitch, int yfirst, int32_t* __restrict__ p32,
-                                                         double* __restrict__ pd, int32_t* __restrict__ hs1, long long* __restrict__ hs2)
+                                                         int32_t* __restrict__ pn, int32_t* __restrict__ hs1, long long* __restrict__ hs2)
 {
     __shared__ int tile[256 + 2 * 16];
     const int y = yfirst + blockIdx.y, x0 = blockIdx.x * 256;
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(256) void ncc16_hsum_kernel(const uint16_t* __restr
     for (int i = 0; i <= 2 * r; i++) { int v = tile[threadIdx.x + i]; s1 += v; s2 += (long long)v * v; }
     const size_t o = (size_t)y * pitch + x;
     p32[o] = tile[threadIdx.x + r];
-    if (pd) pd[o] = (double)tile[threadIdx.x + r];
+    if (pn) pn[o] = (2 * r + 1) * (2 * r + 1) * tile[threadIdx.x + r];       // |N p'| <= 961 * 32768 < 2^31
     hs1[o] = s1; hs2[o] = s2;
 }
 
@@ -102,15 +109,18 @@ struct Ncc16Cfg {
 
 // One wavefront per workgroup = (strip of WT columns, band of rows, chunk of 64 disparities).
 // LDS: 4 arrays (entering right row, leaving right row, S_R, 1/sigma_R) x 4 shifted copies.
+// bit pattern of the double 1.5 * 2^52: an int64 accumulator that starts from it reads, as a double, 1.5 * 2^52 + sum
+#define NCC16_BIAS_BITS 0x4338000000000000LL
+#define NCC16_BIAS 6755399441055744.0
+
 template <int R, int WT>
 __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
-    NccArgs a, const double* __restrict__ gL, const int32_t* __restrict__ gR,
+    NccArgs a, const int32_t* __restrict__ gNL, const int32_t* __restrict__ gR,
     const double* __restrict__ gSL, const int32_t* __restrict__ gSR, const float* __restrict__ gIR,
     float* __restrict__ oKeys)
 {
     using Cfg = Ncc16Cfg<R, WT>;
     constexpr int WN = 2 * R + 1, NC = Cfg::NC, NCP = Cfg::NCP, SEG = Cfg::SEG, LENP = Cfg::LENP;
-    constexpr double NN = (double)(WN * WN);
     __shared__ __attribute__((aligned(16))) int sArr[16 * LENP];
 
     const int lane = threadIdx.x;
@@ -151,69 +161,84 @@ __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
         mycol = (int)ncc_reduce_quads(qi[0], qi[1], qi[2], qi[3], lane);
     }
 
-    double C[NC];
+    long long C[NC];              // N * (column sum of products) + NCC16_BIAS_BITS
 #pragma unroll
-    for (int k = 0; k < NC; k++) C[k] = 0;
+    for (int k = 0; k < NC; k++) C[k] = NCC16_BIAS_BITS;
 
     // The next row is fetched into registers while the current row is processed and written to LDS
     // at the end of the iteration (a wavefront's LDS operations execute in order), so the global
-    // memory latency is hidden behind a whole row of arithmetic.
+    // memory latency is hidden behind a whole row of arithmetic.  Every load is unconditional (column
+    // clamped into the raster, 32-bit lane offset on a wave-uniform row pointer) and the conditions
+    // are applied when the values are published: a load inside a conditional block is a branch and
+    // a wait of its own.
     constexpr int NSTG = (SEG + 63) / 64;
     int nvn[NSTG], nvo[NSTG], nvs[NSTG]; float nvi[NSTG];
-    auto fetch = [&](int ynew, int yout, bool stats, bool warm) {
+    unsigned xcl[NSTG]; bool xin[NSTG];
+#pragma unroll
+    for (int q = 0; q < NSTG; q++) {
+        const int i = lane + 64 * q;
+        const unsigned xr = (unsigned)(xr0 + i);
+        xin[q] = (xr < (unsigned)a.W && i < SEG);               // also false for negative columns
+        xcl[q] = min(xr, (unsigned)(a.W - 1)) * 4u;            // byte offset: scalar row base + 32-bit lane offset addressing
+    }
+    auto fetch = [&](int ynew, int yout, bool stats) {
         const int yold = ynew - WN;
         const int32_t* rn = gR + (size_t)ynew * P;
         const int32_t* ro = gR + (size_t)(yold >= 0 ? yold : 0) * P;
         const int32_t* rs = gSR + (size_t)(stats ? yout : 0) * P;
         const float* ri = gIR + (size_t)(stats ? yout : 0) * P;
-        const bool old_ok = !warm && yold >= 0;
 #pragma unroll
         for (int q = 0; q < NSTG; q++) {
-            const int i = lane + 64 * q;
-            const unsigned xr = (unsigned)(xr0 + i);
-            const bool in = (xr < (unsigned)a.W && i < SEG);
-            nvn[q] = in ? rn[xr] : 0;
-            nvo[q] = (in && old_ok) ? ro[xr] : 0;
-            nvs[q] = (stats && in) ? rs[xr] : 0;
-            nvi[q] = stats ? (in ? ri[xr] : __builtin_nanf("")) : 0.f;
+            nvn[q] = *(const int32_t*)((const char*)rn + xcl[q]); nvo[q] = *(const int32_t*)((const char*)ro + xcl[q]);
+            nvs[q] = *(const int32_t*)((const char*)rs + xcl[q]); nvi[q] = *(const float*)((const char*)ri + xcl[q]);
         }
     };
-    auto publish = [&]() {
+    // warm: nothing leaves the window yet (the leaving row counts as 0); stats: the row carries window statistics
+    auto publish = [&](bool stats, bool old_ok) {
 #pragma unroll
         for (int q = 0; q < NSTG; q++) {
             const int i = lane + 64 * q;
             if (i >= SEG) continue;
+            const int vn = xin[q] ? nvn[q] : 0;
+            const int vo = (xin[q] && old_ok) ? -nvo[q] : 0;     // the leaving row is staged negated (32768 fits an int)
+            const int vs = (xin[q] && stats) ? nvs[q] : 0;
+            const float vi = stats ? (xin[q] ? nvi[q] : __builtin_nanf("")) : 0.f;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int pos = i + ((4 - c) & 3);
-                sArr[(0 * 4 + c) * LENP + pos] = nvn[q];
-                sArr[(1 * 4 + c) * LENP + pos] = -nvo[q];        // the leaving row is staged negated
-                sArr[(2 * 4 + c) * LENP + pos] = nvs[q];
-                sArr[(3 * 4 + c) * LENP + pos] = __builtin_bit_cast(int, nvi[q]);
+                sArr[(0 * 4 + c) * LENP + pos] = vn;
+                sArr[(1 * 4 + c) * LENP + pos] = vo;
+                sArr[(2 * 4 + c) * LENP + pos] = vs;
+                sArr[(3 * 4 + c) * LENP + pos] = __builtin_bit_cast(int, vi);
             }
         }
     };
-    fetch(yb0 - R, yb0 - 2 * R, false, true);
-    publish();
+    fetch(yb0 - R, yb0 - 2 * R, false);
+    publish(false, false);
+
+    // requests written above this fence are issued before the arithmetic below it (the compiler would
+    // otherwise sink every load to its first use, i.e. wait for it on the spot)
+#define NCC16_ISSUED() asm volatile("" ::: "memory")
 
     for (int t = 0; t < T; t++) {
         const int ynew = yb0 - R + t;
         const bool score = (t >= 2 * R);
         const int yout = ynew - R;
         const bool have_next = (t + 1 < T);
-        if (have_next) fetch(ynew + 1, yout + 1, t + 1 >= 2 * R, t + 1 < WN);
+        fetch(have_next ? ynew + 1 : ynew, have_next ? yout + 1 : yout, t + 1 >= 2 * R);     // unconditional; dropped after the last row
+        NCC16_ISSUED();
 
         // ---- column sums, software pipelined: the operands of 4 columns are requested while the
-        // previous 4 are consumed (explicit wait + scheduling barriers keep that order) ----
+        // previous 4 are consumed ----
         {
             const int4* bn4 = (const int4*)(sArr + (0 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
             const int4* bo4 = (const int4*)(sArr + (1 * 4 + cA) * LENP + loff + ((4 - cA) & 3));
-            const double* lnew = gL + (size_t)ynew * P + (x0 - R);
+            const int32_t* lnew = gNL + (size_t)ynew * P + (x0 - R);
             const int yold = ynew - WN;
-            const double* lold = gL + (size_t)(yold >= 0 ? yold : 0) * P + (x0 - R);
+            const int32_t* lold = gNL + (size_t)(yold >= 0 ? yold : 0) * P + (x0 - R);
             constexpr int NGA = NCP / 4;
             int4 bn[2], bo[2];
-            double an[2][4], ao[2][4];
+            int an[2][4], ao[2][4];
             auto loadA = [&](int g, int set) {
                 bn[set] = bn4[g]; bo[set] = bo4[g];
 #pragma unroll
@@ -221,23 +246,25 @@ __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
                     if (4 * g + e < NC) { an[set][e] = lnew[4 * g + e]; ao[set][e] = lold[4 * g + e]; }
             };
             loadA(0, 0);
+            NCC16_ISSUED();
 #pragma unroll
             for (int g = 0; g < NGA; g++) {
                 const int set = g & 1;
                 __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): LDS and scalar loads of this group
                 __builtin_amdgcn_sched_barrier(0);
                 if (g + 1 < NGA) loadA(g + 1, set ^ 1);
+                NCC16_ISSUED();
                 __builtin_amdgcn_sched_barrier(0);
                 const int bnv[4] = { bn[set].x, bn[set].y, bn[set].z, bn[set].w };
                 const int bov[4] = { bo[set].x, bo[set].y, bo[set].z, bo[set].w };
+                // the entering row of all four columns first, then the leaving row: two multiply-adds into
+                // the same accumulator back to back would wait for each other
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int k = 4 * g + e;
-                    if (k < NC) {
-                        C[k] = __builtin_fma(an[set][e], (double)bnv[e], C[k]);
-                        C[k] = __builtin_fma(ao[set][e], (double)bov[e], C[k]);   // bo: negated leaving row, 0 while the window fills
-                    }
-                }
+                for (int e = 0; e < 4; e++)
+                    if (4 * g + e < NC) C[4 * g + e] += (long long)an[set][e] * (long long)bnv[e];      // v_mad_i64_i32
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (4 * g + e < NC) C[4 * g + e] += (long long)ao[set][e] * (long long)bov[e];      // bo: negated leaving row, 0 while the window fills
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -247,11 +274,6 @@ __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
             const int4* sr4 = (const int4*)(sArr + (2 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
             const float4* ir4 = (const float4*)(sArr + (3 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
             const double* slrow = gSL + (size_t)yout * P + (x0 - R);
-            double S = 0.0;
-#pragma unroll
-            for (int k = 0; k < 2 * R; k++) S += C[k];
-            float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
-            NccTree tr;
             constexpr int NGB = WT / 4;
             int4 s4[2]; float4 i4[2]; double sl[2][4];
             auto loadB = [&](int g, int set) {
@@ -260,30 +282,47 @@ __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
                 for (int e = 0; e < 4; e++) sl[set][e] = slrow[4 * g + e];
             };
             loadB(0, 0);
+            NCC16_ISSUED();
+            // window sum of the first output column: 2R+1 accumulators added as integers (each carries the
+            // bias constant once), all but one bias removed, the last one by the binary64 subtraction
+            double S;
+            {
+                long long si = C[0];
+#pragma unroll
+                for (int k = 1; k <= 2 * R; k++) si += C[k];
+                si -= (long long)((unsigned long long)NCC16_BIAS_BITS * (unsigned long long)(2 * R));    // wraps like the sum did
+                S = __builtin_bit_cast(double, si) - NCC16_BIAS;
+            }
+            float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
+            NccTree tr;
 #pragma unroll
             for (int g = 0; g < NGB; g++) {
                 const int set = g & 1;
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_sched_barrier(0);
                 if (g + 1 < NGB) loadB(g + 1, set ^ 1);
+                NCC16_ISSUED();
                 __builtin_amdgcn_sched_barrier(0);
                 const int srv[4] = { s4[set].x, s4[set].y, s4[set].z, s4[set].w };
                 const float irv[4] = { i4[set].x, i4[set].y, i4[set].z, i4[set].w };
+                float sc[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int j = 4 * g + e;
-                    S += C[j + 2 * R];
-                    const double num = __builtin_fma(NN, S, -(sl[set][e] * (double)srv[e]));   // exact: integers below 2^53
-                    const float sc = __builtin_fmaf((float)num, irv[e], bias);
-                    S -= C[j];
-                    tr.push(j & 15, ncc_make_key(sc, tag));
+                    // N*S_LR - S_L*S_R, exact: integers below 2^53
+                    const double num = __builtin_fma(-sl[set][e], (double)srv[e], S);
+                    sc[e] = __builtin_fmaf((float)num, irv[e], bias);
+                    // slide: the difference of two biased accumulators read as doubles is their exact integer difference
+                    if (j + 1 < WT)
+                        S += __builtin_bit_cast(double, C[j + 1 + 2 * R]) - __builtin_bit_cast(double, C[j]);
                 }
+                tr.push4((4 * g) & 15, sc[0], sc[1], sc[2], sc[3], tag);
                 if ((g & 3) == 3) q[g >> 2] = tr.q;
                 __builtin_amdgcn_sched_barrier(0);
             }
             red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
         }
-        if (have_next) publish();
+        publish(t + 1 >= 2 * R, t + 1 >= WN && ynew + 1 - WN >= 0);
         // the store comes after publish: vector memory operations complete in order, and publish
         // waits for the prefetched row
         if (score) {
@@ -292,6 +331,7 @@ __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
                 oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red;
         }
     }
+#undef NCC16_ISSUED
 }
 
 // Merge of the chunk keys, exact scores of the winner and its two neighbours by direct window sums.
@@ -422,9 +462,9 @@ static int ncc16_prepare(mis_ctx* ctx, int window, int need_lo, int need_hi)
     const size_t npx = (size_t)pitch * H;
     if (w->cap_px < npx) {
         void** b4[] = { (void**)&w->L32, (void**)&w->R32, (void**)&w->SL, (void**)&w->SR, (void**)&w->iL, (void**)&w->iR,
-                        (void**)&w->hs1 };
+                        (void**)&w->hs1, (void**)&w->NL };
         for (void** b : b4) { if (*b) { MIS_HIP(ctx, hipFree(*b)); *b = nullptr; } }
-        void** b8[] = { (void**)&w->hs2, (void**)&w->Ld, (void**)&w->SLd };
+        void** b8[] = { (void**)&w->hs2, (void**)&w->SLd };
         for (void** b : b8) { if (*b) { MIS_HIP(ctx, hipFree(*b)); *b = nullptr; } }
         w->cap_px = 0;
         for (void** b : b4) MIS_HIP(ctx, hipMalloc(b, npx * 4));
@@ -462,9 +502,9 @@ static int ncc16_prepare(mis_ctx* ctx, int window, int need_lo, int need_hi)
         const dim3 grid((pitch + 255) / 256, h1 - h0);
         const dim3 sgrid((pitch + 255) / 256, (hi[k] - lo[k] + NCC16_STATS_BAND - 1) / NCC16_STATS_BAND);
         const int band0 = lo[k] / NCC16_STATS_BAND;
-        hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[0], stride_px, W, H, r, pitch, h0, w->L32, w->Ld, w->hs1, w->hs2);
+        hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[0], stride_px, W, H, r, pitch, h0, w->L32, w->NL, w->hs1, w->hs2);
         hipLaunchKernelGGL(ncc16_stats_kernel<true>, sgrid, block, 0, s, W, H, r, pitch, band0, w->hs1, w->hs2, w->SL, w->iL, w->SLd);
-        hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[1], stride_px, W, H, r, pitch, h0, w->R32, (double*)nullptr, w->hs1, w->hs2);
+        hipLaunchKernelGGL(ncc16_hsum_kernel, grid, block, 0, s, (const uint16_t*)ctx->img[1], stride_px, W, H, r, pitch, h0, w->R32, (int32_t*)nullptr, w->hs1, w->hs2);
         hipLaunchKernelGGL(ncc16_stats_kernel<false>, sgrid, block, 0, s, W, H, r, pitch, band0, w->hs1, w->hs2, w->SR, w->iR, (double*)nullptr);
     }
     MIS_HIP(ctx, hipGetLastError());
@@ -486,7 +526,7 @@ static int ncc16_launch(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, i
     a.nstrips = (a.W - 2 * R + WT - 1) / WT;
     a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
     hipLaunchKernelGGL((ncc16_argmax_kernel<R, WT>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
-                       a, w->Ld, w->R32, w->SLd, w->SR, w->iR, w->keys);
+                       a, w->NL, w->R32, w->SLd, w->SR, w->iR, w->keys);
     mis_prof_mark(ctx);
     {
         const size_t lds = Ncc16RefineCfg<R>::lds_bytes(a.dmax - a.dmin + 1);

@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmistereo.so")
+# MISTEREO_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("MISTEREO_LIB") or os.path.join(_HERE, "libmistereo.so")
 
 U8, U16, F32 = 0, 1, 2
 INVALID_DISP = -32768
