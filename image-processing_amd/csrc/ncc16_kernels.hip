@@ -103,7 +103,7 @@ template <int R, int WT>
 struct Ncc16Cfg {
     static constexpr int NC = WT + 2 * R;
     static constexpr int NCP = (NC + 3) & ~3;
-    static constexpr int SEG = NCP + 64 + 4;
+    static constexpr int SEG = NCP + 63;                           // staged right-image columns: lane l reads elements 63-l .. 63-l+NCP-1
     static constexpr int LENP = ((SEG + 3 + 47) / 64) * 64 + 16;
 };
 
@@ -183,14 +183,18 @@ __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
     }
     auto fetch = [&](int ynew, int yout, bool stats) {
         const int yold = ynew - WN;
-        const int32_t* rn = gR + (size_t)ynew * P;
-        const int32_t* ro = gR + (size_t)(yold >= 0 ? yold : 0) * P;
-        const int32_t* rs = gSR + (size_t)(stats ? yout : 0) * P;
-        const float* ri = gIR + (size_t)(stats ? yout : 0) * P;
+        // one buffer descriptor per table row: scalar base, 32-bit lane offset (no 64-bit address arithmetic per load)
+        auto rowbuf = [&](const void* base, int row) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + (size_t)row * P * 4), 0, P * 4, 0x00027000);
+        };
+        const __amdgpu_buffer_rsrc_t rn = rowbuf(gR, ynew), ro = rowbuf(gR, yold >= 0 ? yold : 0);
+        const __amdgpu_buffer_rsrc_t rs = rowbuf(gSR, stats ? yout : 0), ri = rowbuf(gIR, stats ? yout : 0);
 #pragma unroll
         for (int q = 0; q < NSTG; q++) {
-            nvn[q] = *(const int32_t*)((const char*)rn + xcl[q]); nvo[q] = *(const int32_t*)((const char*)ro + xcl[q]);
-            nvs[q] = *(const int32_t*)((const char*)rs + xcl[q]); nvi[q] = *(const float*)((const char*)ri + xcl[q]);
+            nvn[q] = __builtin_amdgcn_raw_buffer_load_b32(rn, xcl[q], 0, 0);
+            nvo[q] = __builtin_amdgcn_raw_buffer_load_b32(ro, xcl[q], 0, 0);
+            nvs[q] = __builtin_amdgcn_raw_buffer_load_b32(rs, xcl[q], 0, 0);
+            nvi[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, xcl[q], 0, 0));
         }
     };
     // warm: nothing leaves the window yet (the leaving row counts as 0); stats: the row carries window statistics
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
     const bool valid = inside && ds != MIS_INVALID_DISP;
     const int u = valid ? x - ds : x0 - a.dmax;   // window centre in the right image (any in-range value when idle)
     const int cbase = x0 - a.dmax - R - 1;        // raster column of right-tile column 0
-    double Sm = 0.0, S0 = 0.0, Sp = 0.0;          // disparities ds-1, ds, ds+1 <-> right columns u+1, u, u-1
+    long long Sm = 0, S0 = 0, Sp = 0;             // disparities ds-1, ds, ds+1 <-> right columns u+1, u, u-1 (exact 64-bit sums)
     const int32_t* pl = tL + lx;                              // column x-R
     const int32_t* pr = tR + (u - R - 1 - cbase);             // column u-R-1
 
@@ -411,22 +415,22 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
             if (row < y - R || row > y + R) continue;          // wave-uniform: a wavefront is one row
             const int32_t* plj = pl + j * LC;
             const int32_t* prj = pr + j * NC;
-            double rc = (double)prj[0], rb = (double)prj[1];
+            int rc = prj[0], rb = prj[1];
 #pragma unroll
             for (int i = 0; i <= 2 * R; i++) {
-                const double ra = (double)prj[i + 2];
-                const double l = (double)plj[i];
-                Sm = __builtin_fma(l, ra, Sm);
-                S0 = __builtin_fma(l, rb, S0);
-                Sp = __builtin_fma(l, rc, Sp);
+                const int ra = prj[i + 2];
+                const int l = plj[i];
+                Sm += (long long)l * (long long)ra;          // v_mad_i64_i32: multiply and 64-bit accumulate in one instruction
+                S0 += (long long)l * (long long)rb;
+                Sp += (long long)l * (long long)rc;
                 rc = rb; rb = ra;
             }
         }
     }
     if (!valid) return;
 
-    constexpr double NN = (double)((2 * R + 1) * (2 * R + 1));
-    const double sl = (double)gSL[(size_t)y * P + (x - R)];
+    constexpr long long NN = (long long)((2 * R + 1) * (2 * R + 1));
+    const long long sl = (long long)gSL[(size_t)y * P + (x - R)];
     const float il = gIL[(size_t)y * P + (x - R)];
     // table values of the three candidates: loaded together (clamped columns), range tests afterwards
     int srv[3]; float irv[3];
@@ -436,10 +440,10 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
         srv[k] = gSR[(size_t)y * P + col];
         irv[k] = gIR[(size_t)y * P + col];
     }
-    auto score = [&](double S, int k, int col, int d) -> float {
+    auto score = [&](long long S, int k, int col, int d) -> float {
         if (d < a.dmin || d > a.dmax || col < 0 || col >= a.W) return __builtin_nanf("");
-        const double num = __builtin_fma(NN, S, -(sl * (double)srv[k]));
-        return __builtin_fmaf((float)num, irv[k], 0.f);
+        const long long num = NN * S - sl * (long long)srv[k];          // exact, below 2^53 in magnitude
+        return __builtin_fmaf((float)(double)num, irv[k], 0.f);         // rounded once to binary32, like the argmax kernel's conversion
     };
     const float sm = score(Sm, 0, u + 1, ds - 1), s0 = score(S0, 1, u, ds), sp = score(Sp, 2, u - 1, ds + 1);
     float delta = 0.f;
