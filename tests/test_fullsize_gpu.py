@@ -125,3 +125,71 @@ def test_a_strip_builds_only_its_rows_of_tables(ctx, full):
     assert np.array_equal(d[3072:4096].cpu().numpy().view(np.uint32), out["disp"][3072:4096].view(np.uint32))
     assert times["strip"][0] <= 0.3 * times["full"][0], times
     assert times["strip"][1] <= 0.2 * times["full"][1], times
+
+
+def test_config3_strip_of_a_16384_frame(ctx):
+    """BASELINE config[3]: one 16384 x 16384 8-bit pair, 21 x 21 window, +-256 search, sharded by row
+    strips: the strip one of 8 ranks computes (2048 rows from row 7168) inside the full-size frame
+    (64-bit row offsets, 1.1 GB tables for the strip only), bit for bit equal to the same rows computed
+    as a raster of their own (strip + halo, what a rank that holds only its strip binds), and against
+    the oracle on a 160-row band of it."""
+    import torch
+    W = H = 16384
+    row0, n, r = 7168, 2048, WIN // 2
+    band_l = synth.texture(n + 2 * r, W, 0xC0FFEE + 3)
+    band_r = synth.shift_right_image(band_l, synth.planar_disparity(n + 2 * r, W, -200, 200, 64, 5), fill_seed=6)
+    tl = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    tr = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    tl[row0 - r:row0 + n + r] = torch.from_numpy(band_l).cuda()
+    tr[row0 - r:row0 + n + r] = torch.from_numpy(band_r).cuda()
+    d = torch.full((H, W), -7.0, dtype=torch.float32, device="cuda"); p = torch.full_like(d, -7.0)
+    torch.cuda.synchronize()
+    ctx.bind_pair_torch(tl, tr)
+    ctx.ncc_dense_torch(WIN, -D, D, d, p, row0=row0, nrows=n)
+    ctx.synchronize()
+    assert float(d[row0 - 1].max()) == -7.0 and float(d[row0 + n].max()) == -7.0      # rows outside the strip untouched
+    strip_d, strip_p = d[row0:row0 + n].cpu().numpy(), p[row0:row0 + n].cpu().numpy()
+    del d, p, tl, tr
+    torch.cuda.empty_cache()
+    # the same rows as a raster of their own
+    bl, br = torch.from_numpy(band_l).cuda(), torch.from_numpy(band_r).cuda()
+    d2 = torch.empty((n + 2 * r, W), dtype=torch.float32, device="cuda"); p2 = torch.empty_like(d2)
+    i2 = torch.empty((n + 2 * r, W), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    ctx.bind_pair_torch(bl, br)
+    ctx.ncc_dense_torch(WIN, -D, D, d2, p2, i2)
+    ctx.synchronize()
+    assert np.array_equal(d2[r:r + n].cpu().numpy().view(np.uint32), strip_d.view(np.uint32))
+    assert np.array_equal(p2[r:r + n].cpu().numpy().view(np.uint32), strip_p.view(np.uint32))
+    # the oracle on 160 rows of the band
+    y0, m = 900, 160
+    cl, cr = np.ascontiguousarray(band_l[y0 - r:y0 + m + r]), np.ascontiguousarray(band_r[y0 - r:y0 + m + r])
+    ora = oracle.ncc_dense(cl, cr, WIN, -D, D)
+    gd = np.full(cl.shape, -32768, np.float32); gp = np.zeros(cl.shape, np.float32); gi = np.full(cl.shape, -32768, np.int16)
+    gd[r:-r] = d2[y0:y0 + m].cpu().numpy(); gp[r:-r] = p2[y0:y0 + m].cpu().numpy(); gi[r:-r] = i2[y0:y0 + m].cpu().numpy()
+    rep = oracle.parity_report(gd, gp, ora, cl, cr, WIN, -D, D, gpu_idisp=gi)
+    assert rep["validity_masks_equal"] and rep["argmax_agree"] >= 0.999 and rep["argmax_diffs_all_near_tie"], rep
+    assert rep["peak_within_1e-4"] == 1.0, rep
+    assert rep["subpx_outliers"] == rep["subpx_outliers_ill_conditioned"], rep
+
+
+def test_config4_band_16384_wide_u16(ctx):
+    """BASELINE config[4]'s frame width and search: a 16384-wide, 126-row 16-bit band, 31 x 31 window,
+    +-512 search (1025 disparities, 17 chunks), subpixel shift 37.25 px, against the oracle."""
+    W, Hb, win, Dm = 16384, 126, 31, 512
+    rng = np.random.default_rng(9)
+    left = synth.texture(Hb, W, 0xC0FFEE + 5, np.uint16).astype(np.int64) + rng.integers(-120, 121, (Hb, W))
+    left = np.clip(left, 0, 65535).astype(np.uint16)
+    right = synth.shift_right_image_subpixel(left, 37.25)
+    right[:, 9000:] = synth.shift_right_image(left, -480, fill_seed=3)[:, 9000:]      # a plane near the end of the range
+    ctx.upload_pair(left, right)
+    out = ctx.ncc_dense(win, -Dm, Dm)
+    ora = oracle.ncc_dense(left, right, win, -Dm, Dm)
+    rep = oracle.parity_report(out["disp"], out["peak"], ora, left, right, win, -Dm, Dm, gpu_idisp=out["idisp"])
+    assert rep["validity_masks_equal"] and rep["argmax_agree"] >= 0.999 and rep["argmax_diffs_all_near_tie"], rep
+    assert rep["peak_within_1e-4"] == 1.0, rep
+    assert rep["subpx_outliers"] == rep["subpx_outliers_ill_conditioned"], rep
+    core = out["idisp"][20:-20, 600:8000]
+    assert (core == 37).mean() > 0.99
+    sub = out["disp"][20:-20, 600:8000][core == 37]
+    assert abs(float(sub.mean()) - 37.25) < 0.05           # linear resampling biases the parabola slightly
