@@ -113,11 +113,13 @@ struct Ncc16Cfg {
 #define NCC16_BIAS_BITS 0x4338000000000000LL
 #define NCC16_BIAS 6755399441055744.0
 
-template <int R, int WT>
+// WANT2: second key plane (best key among the lanes further than one lane from the column's winner),
+// as in the 8-bit kernel.
+template <int R, int WT, bool WANT2>
 __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
     NccArgs a, const int32_t* __restrict__ gNL, const int32_t* __restrict__ gR,
     const double* __restrict__ gSL, const int32_t* __restrict__ gSR, const float* __restrict__ gIR,
-    float* __restrict__ oKeys)
+    float* __restrict__ oKeys, float* __restrict__ oKeys2)
 {
     using Cfg = Ncc16Cfg<R, WT>;
     constexpr int WN = 2 * R + 1, NC = Cfg::NC, NCP = Cfg::NCP, SEG = Cfg::SEG, LENP = Cfg::LENP;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
             }
         }
 
-        float red = 0.f;
+        float red = 0.f, red2 = 0.f;
         if (score) {
             const int4* sr4 = (const int4*)(sArr + (2 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
             const float4* ir4 = (const float4*)(sArr + (3 * 4 + cB) * LENP + offB + ((4 - cB) & 3));
@@ -298,7 +300,9 @@ __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
                 S = __builtin_bit_cast(double, si) - NCC16_BIAS;
             }
             float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
-            NccTree tr;
+            float q2[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
+            NccTree tr, tr2;
+            float kk[WANT2 ? 16 : 1];                           // keys of the current block of 16 columns
 #pragma unroll
             for (int g = 0; g < NGB; g++) {
                 const int set = g & 1;
@@ -320,19 +324,34 @@ __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
                     if (j + 1 < WT)
                         S += __builtin_bit_cast(double, C[j + 1 + 2 * R]) - __builtin_bit_cast(double, C[j]);
                 }
-                tr.push4((4 * g) & 15, sc[0], sc[1], sc[2], sc[3], tag);
-                if ((g & 3) == 3) q[g >> 2] = tr.q;
+                if constexpr (WANT2) {
+                    tr.push4_keep((4 * g) & 15, sc[0], sc[1], sc[2], sc[3], tag);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) kk[((4 * g) & 15) + e] = sc[e];
+                } else {
+                    tr.push4((4 * g) & 15, sc[0], sc[1], sc[2], sc[3], tag);
+                }
+                if ((g & 3) == 3) {
+                    q[g >> 2] = tr.q;
+                    if constexpr (WANT2) {
+                        ncc_second_pass16(kk, ncc_quad_full(tr.q), -3.0e38f, tr2);
+                        q2[g >> 2] = tr2.q;
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
+            if constexpr (WANT2) red2 = ncc_reduce_quads(q2[0], q2[1], q2[2], q2[3], lane);
         }
         publish(t + 1 >= 2 * R, t + 1 >= WN && ynew + 1 - WN >= 0);
         // the store comes after publish: vector memory operations complete in order, and publish
         // waits for the prefetched row
         if (score) {
             const int x = x0 + mycol;
-            if (mycol < WT && x < a.W - R)
+            if (mycol < WT && x < a.W - R) {
                 oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red;
+                if constexpr (WANT2) oKeys2[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red2;
+            }
         }
     }
 #undef NCC16_ISSUED
@@ -352,12 +371,16 @@ struct Ncc16RefineCfg {
     static size_t lds_bytes(int nd) { return (size_t)NCC16_REF_G * (LC + right_cols(nd)) * sizeof(int32_t); }
 };
 
-template <int R>
+// WANT2: second-peak output from the two key planes, with the exact score of the disparity two away
+// from the winner where a chunk boundary hid it (see ncc_refine_kernel in ncc_kernels.hip); that
+// candidate's window sum rides along with the other three.
+template <int R, bool WANT2>
 __global__ __launch_bounds__(512) void ncc16_refine_kernel(
     NccArgs a, const int32_t* __restrict__ gL, const int32_t* __restrict__ gR,
     const int32_t* __restrict__ gSL, const float* __restrict__ gIL, const int32_t* __restrict__ gSR,
     const float* __restrict__ gIR, const float* __restrict__ gKeys, int nchunk,
-    float* __restrict__ oDisp, float* __restrict__ oPeak, int16_t* __restrict__ oIdisp)
+    float* __restrict__ oDisp, float* __restrict__ oPeak, int16_t* __restrict__ oIdisp,
+    const float* __restrict__ gKeys2, float* __restrict__ oPeak2)
 {
     constexpr int LC = Ncc16RefineCfg<R>::LC, G = NCC16_REF_G;
     extern __shared__ int32_t ncc16_refine_lds[];
@@ -388,14 +411,35 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
             }
         }
         if (oIdisp) oIdisp[o] = (int16_t)ds;
-        if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; }
+        if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; if (WANT2) oPeak2[o] = -1.f; }
     }
     const bool valid = inside && ds != MIS_INVALID_DISP;
+    float sec = -1.0e30f;                         // WANT2: best second-peak candidate (argmax-kernel scale)
+    int xd = 0;                                   // WANT2: +2 / -2 when the disparity two away needs its exact score
+    if (WANT2 && valid) {
+        const size_t plane = (size_t)a.H * a.out_pitch;
+        const int bc = (ds - a.dmin) >> 6, lw = (ds - a.dmin) & 63;
+        for (int c = 0; c < nchunk; c++) {
+            const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * plane + o]);
+            const int l1 = 63 - (int)(kb & 63u);
+            bool second_plane = (c == bc);
+            if (c == bc + 1 && lw == 63 && l1 == 0) { second_plane = true; xd = 2; }
+            if (c == bc - 1 && lw == 0 && l1 == 63) { second_plane = true; xd = -2; }
+            const uint32_t vb = second_plane ? __builtin_bit_cast(uint32_t, gKeys2[(size_t)c * plane + o]) : kb;
+            const float v = __builtin_bit_cast(float, vb & 0xFFFFFFC0u);
+            if (v > sec) sec = v;
+        }
+    }
     const int u = valid ? x - ds : x0 - a.dmax;   // window centre in the right image (any in-range value when idle)
     const int cbase = x0 - a.dmax - R - 1;        // raster column of right-tile column 0
     long long Sm = 0, S0 = 0, Sp = 0;             // disparities ds-1, ds, ds+1 <-> right columns u+1, u, u-1 (exact 64-bit sums)
+    long long Sx = 0;                             // WANT2: disparity ds + xd <-> right column u - xd
+    const int d2 = ds + xd;
+    const bool need = WANT2 && valid && xd != 0 && d2 >= a.dmin && d2 <= a.dmax;
+    const int u2 = need ? x - d2 : u;
     const int32_t* pl = tL + lx;                              // column x-R
     const int32_t* pr = tR + (u - R - 1 - cbase);             // column u-R-1
+    const int32_t* px = tR + (u2 - R - cbase);                // column u2-R
 
     const int ylo = y0 - R, yhi = min(y0 + 3, a.row1 - 1) + R;   // window rows of the 4 output rows
     for (int yg = ylo; yg <= yhi; yg += G) {
@@ -416,6 +460,7 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
             const int32_t* plj = pl + j * LC;
             const int32_t* prj = pr + j * NC;
             int rc = prj[0], rb = prj[1];
+            const int32_t* pxj = px + j * NC;
 #pragma unroll
             for (int i = 0; i <= 2 * R; i++) {
                 const int ra = prj[i + 2];
@@ -423,6 +468,7 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
                 Sm += (long long)l * (long long)ra;          // v_mad_i64_i32: multiply and 64-bit accumulate in one instruction
                 S0 += (long long)l * (long long)rb;
                 Sp += (long long)l * (long long)rc;
+                if constexpr (WANT2) Sx += (long long)l * (long long)pxj[i];
                 rc = rb; rb = ra;
             }
         }
@@ -453,6 +499,14 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
     }
     oDisp[o] = (float)ds + delta;
     oPeak[o] = s0 * il;
+    if constexpr (WANT2) {
+        if (need && u2 >= 0 && u2 < a.W) {
+            const long long num = NN * Sx - sl * (long long)gSR[(size_t)y * P + u2];
+            const float sx = __builtin_fmaf((float)(double)num, gIR[(size_t)y * P + u2], 0.f);     // NaN where the window does not fit
+            if (sx > sec) sec = sx;
+        }
+        oPeak2[o] = (sec > -1.0e30f) ? sec * il : -1.f;
+    }
 }
 
 // tables for raster rows [need_lo, need_hi) (the rows the requested output rows read); rows built by
@@ -520,39 +574,42 @@ static int ncc16_prepare(mis_ctx* ctx, int window, int need_lo, int need_hi)
     return MIS_OK;
 }
 
-template <int R>
-static int ncc16_launch(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
+template <int R, bool WANT2>
+static int ncc16_launch(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
 {
     constexpr int WT = 32;
     Ncc16Ws* w = ctx->ncc16;
-    int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, (size_t)a.nchunk * a.H * a.W * sizeof(float));
+    const size_t plane_px = (size_t)a.H * a.W;
+    int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, (size_t)a.nchunk * plane_px * sizeof(float) * (WANT2 ? 2 : 1));
     if (rc) return rc;
+    float* keys2 = WANT2 ? w->keys + (size_t)a.nchunk * plane_px : nullptr;
     a.nstrips = (a.W - 2 * R + WT - 1) / WT;
     a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
-    hipLaunchKernelGGL((ncc16_argmax_kernel<R, WT>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
-                       a, w->NL, w->R32, w->SLd, w->SR, w->iR, w->keys);
+    hipLaunchKernelGGL((ncc16_argmax_kernel<R, WT, WANT2>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
+                       a, w->NL, w->R32, w->SLd, w->SR, w->iR, w->keys, keys2);
     mis_prof_mark(ctx);
     {
         const size_t lds = Ncc16RefineCfg<R>::lds_bytes(a.dmax - a.dmin + 1);
         if (lds > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc16_refine_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ncc16_refine_kernel<R>, dim3((a.W - 2 * R + NCC16_REF_BW - 1) / NCC16_REF_BW, (a.row1 - a.row0 + 3) / 4),
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc16_refine_kernel<R, WANT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ncc16_refine_kernel<R, WANT2>), dim3((a.W - 2 * R + NCC16_REF_BW - 1) / NCC16_REF_BW, (a.row1 - a.row0 + 3) / 4),
                            dim3(512), lds, ctx->stream,
-                           a, w->L32, w->R32, w->SL, w->iL, w->SR, w->iR, w->keys, a.nchunk, d_disp, d_peak, d_idisp);
+                           a, w->L32, w->R32, w->SL, w->iL, w->SR, w->iR, w->keys, a.nchunk, d_disp, d_peak, d_idisp, keys2, d_peak2);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
 
 // called by the dense-NCC entry points for 16-bit pairs; a: geometry already filled in
-int mis_ncc16_run(mis_ctx* ctx, int window, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
+int mis_ncc16_run(mis_ctx* ctx, int window, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
 {
     const int r = window / 2;
     int rc = ncc16_prepare(ctx, window, a.row0 - r, a.row1 + r);      // a.row0 / a.row1: output rows, clipped to [r, H-r)
     if (rc) return rc;
     a.pitch = ctx->ncc16->pitch;
     mis_prof_mark(ctx);
-#define NCC16_CASE(RR) case RR: rc = ncc16_launch<RR>(ctx, a, d_disp, d_peak, d_idisp); break;
+#define NCC16_CASE(RR) case RR: rc = d_peak2 ? ncc16_launch<RR, true>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
+                                 : ncc16_launch<RR, false>(ctx, a, d_disp, d_peak, d_idisp, nullptr); break;
     switch (window / 2) {
         NCC16_CASE(1) NCC16_CASE(2) NCC16_CASE(3) NCC16_CASE(4) NCC16_CASE(5) NCC16_CASE(6) NCC16_CASE(7) NCC16_CASE(8)
         NCC16_CASE(9) NCC16_CASE(10) NCC16_CASE(11) NCC16_CASE(12) NCC16_CASE(13) NCC16_CASE(14) NCC16_CASE(15)

@@ -3,14 +3,14 @@
 // What is computed (per left pixel, per disparity d):
 //   score(d) = cov(L window, R window shifted by d) / sqrt(var L * var R)
 // with the first maximum over d, its two neighbours (parabolic subpixel) and optionally the best
-// score further than 1 px away.  This is the dense mode the reference leaves disabled
+// score further than 1 px away (second peak).  This is the dense mode the reference leaves disabled
 // (image3.cpp:775-811) and names as a TODO (image3.cpp:866-870); sign and tie-break follow
 // image3.cpp:696-699 and image3.cpp:486-501.
 //
 // Mapping onto the machine
 //   lane        <-> disparity (64 consecutive d per wavefront, one "chunk")
-//   wavefront   <-> one chunk of disparities for a strip of WT pixel columns, walking down rows
-//   workgroup   <-> all chunks of the disparity range for that strip (<= 16 wavefronts)
+//   wavefront   <-> one chunk of disparities for a strip of WT pixel columns, walking down a band of rows
+//   workgroup   <-> one wavefront; wavefronts never synchronise with each other
 // so every window sum is a running sum held in one lane's registers: the column sums of the
 // product image slide down the rows (one v_dot2c_f32_f16 per column, row and disparity: it adds
 // the entering row's product and subtracts the leaving row's), the window sum slides along the
@@ -244,281 +244,10 @@ __global__ __launch_bounds__(256) void ncc_vpack_kernel(const T* __restrict__ im
 }
 
 // ---------------------------------------------------------------------------------------------
-// Main kernel
-// ---------------------------------------------------------------------------------------------
-
-#define DPP_QUAD_1032 0xB1
-#define DPP_QUAD_2301 0x4E
-#define DPP_ROW_ROR4 0x124
-#define DPP_ROW_ROR8 0x128
-#define DPP_ROW_BCAST15 0x142
-#define DPP_ROW_BCAST31 0x143
-
-template <int CTRL, int ROWMASK = 0xF>
-__device__ __forceinline__ float dpp_f(float v)
-{
-    int i = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, ROWMASK, 0xF, false));
-}
-
-// maximum over the 64 lanes, NaN operands ignored; every lane may hold a different partial value
-// afterwards, lane 63 holds the full maximum
-__device__ __forceinline__ float wave_max_to_lane63(float v)
-{
-    v = fmaxf(v, dpp_f<DPP_QUAD_1032>(v));
-    v = fmaxf(v, dpp_f<DPP_QUAD_2301>(v));
-    v = fmaxf(v, dpp_f<DPP_ROW_ROR4>(v));
-    v = fmaxf(v, dpp_f<DPP_ROW_ROR8>(v));
-    v = fmaxf(v, dpp_f<DPP_ROW_BCAST15, 0xA>(v));
-    v = fmaxf(v, dpp_f<DPP_ROW_BCAST31, 0xC>(v));
-    return v;
-}
-
-__device__ __forceinline__ float readlane_f(float v, int lane)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-// old with lane `lane` (a compile-time constant after unrolling) replaced by the wave-uniform val
-__device__ __forceinline__ float writelane_f(float val, int lane, float old)
-{
-    int sval = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, val));
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(lane));
-    return old;
-}
-
-// result fields exchanged between the chunk wavefronts of a workgroup, per column
-enum { F_BEST = 0, F_IDX, F_SM, F_SP, F_E0, F_E63, F_SEC, NFIELD };
-
-template <int R, int WT, bool WANT2>
-__global__ __launch_bounds__(1024) void ncc_main_kernel(
-    NccArgs a,
-    const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
-    const float* __restrict__ gIL, const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr,
-    const float* __restrict__ gRir, float* __restrict__ oDisp, float* __restrict__ oPeak,
-    int16_t* __restrict__ oIdisp, float* __restrict__ oPeak2)
-{
-    constexpr int WN = 2 * R + 1;
-    constexpr int NC = WT + 2 * R;          // column sums held per lane
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-
-    const int lane = threadIdx.x & 63;
-    const int chunk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nchunk = a.nchunk;
-    const int nthreads = nchunk * 64;
-    const int LEN = NC + nchunk * 64;        // staged right-image columns per row
-
-    float* sBp = (float*)smem_raw;                 // [2][LEN] packed half2 pairs (as raw dwords)
-    float* sSR = sBp + 2 * LEN;                    // [2][LEN]
-    float* sIR = sSR + 2 * LEN;                    // [2][LEN]
-    float* sRes = sIR + 2 * LEN;                   // [2][nchunk][NFIELD][WT]
-
-    const int x0 = R + blockIdx.x * WT;            // first output column of the strip
-    const int yb0 = a.row0 + blockIdx.y * a.band_rows;
-    const int yb1 = min(yb0 + a.band_rows, a.row1);
-    if (yb0 >= yb1) return;
-    const int nrows = yb1 - yb0;
-    const int T = 2 * R + nrows;                   // row steps: 2R warm-up + one per output row
-
-    const int dtop = a.dmin + nchunk * 64 - 1;     // largest disparity any lane stands for
-    const int d = a.dmin + chunk * 64 + lane;      // this lane's disparity
-    const int loff = dtop - d;                     // LDS index of (column k, this lane) is k + loff
-    const int xr0 = x0 - R - dtop;                 // raster column of LDS index 0
-    const float bias = (d <= a.dmax) ? 0.f : -INFINITY;
-
-    float C[NC];
-#pragma unroll
-    for (int k = 0; k < NC; k++) C[k] = 0.f;
-
-    const int P = a.pitch;
-
-    // ---- stage step 0 ----
-    {
-        const int ynew = yb0 - R;
-        for (int i = threadIdx.x; i < LEN; i += nthreads) {
-            int xr = xr0 + i;
-            bool in = (xr >= 0 && xr < a.W);
-            uint32_t bp = in ? gRpack[(size_t)ynew * P + xr] : 0u;
-            sBp[i] = __builtin_bit_cast(float, bp);
-        }
-    }
-    __syncthreads();
-
-    for (int t = 0; t < T; t++) {
-        const int buf = t & 1;
-        const int ynew = yb0 - R + t;              // row entering the window
-        const bool warm = (t < WN);                // leaving row is above the first window: ignore it
-        const bool score = (t >= 2 * R);
-        const int yout = ynew - R;
-
-        // ---- prefetch next step's right-image row into registers ----
-        uint32_t nbp[2] = { 0u, 0u };
-        float nsr[2] = { 0.f, 0.f }, nir[2] = { 0.f, 0.f };
-        const bool have_next = (t + 1 < T);
-        const bool next_score = (t + 1 >= 2 * R);
-        if (have_next) {
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                int i = threadIdx.x + q * nthreads;
-                if (i < LEN) {
-                    int xr = xr0 + i;
-                    bool in = (xr >= 0 && xr < a.W);
-                    nbp[q] = in ? gRpack[(size_t)(ynew + 1) * P + xr] : 0u;
-                    if (next_score) {
-                        nsr[q] = in ? gRsr[(size_t)(yout + 1) * P + xr] : 0.f;
-                        nir[q] = in ? gRir[(size_t)(yout + 1) * P + xr] : __builtin_nanf("");
-                    }
-                }
-            }
-        }
-
-        // ---- column sums: add the entering row, drop the leaving row ----
-        const float* bp = sBp + buf * LEN + loff;
-        const uint32_t* lrow = gLpack + (size_t)ynew * P + (x0 - R);
-        const uint32_t amask = warm ? 0x0000FFFFu : 0xFFFFFFFFu;
-#pragma unroll
-        for (int k = 0; k < NC; k++) {
-            uint32_t av = lrow[k] & amask;
-            half2_t ah = __builtin_bit_cast(half2_t, av);
-            half2_t bh = __builtin_bit_cast(half2_t, bp[k]);
-            C[k] = __builtin_amdgcn_fdot2(ah, bh, C[k], false);
-        }
-
-        if (score) {
-            const float* sr = sSR + buf * LEN + loff + R;
-            const float* ir = sIR + buf * LEN + loff + R;
-            const float* ncrow = gNegc + (size_t)yout * P + (x0 - R);
-            const float* ngrow = gNegg + (size_t)yout * P + (x0 - R);
-            float rBest = -INFINITY, rIdx = 0.f, rSm = 0.f, rSp = 0.f, rE0 = 0.f, rE63 = 0.f, rSec = -INFINITY;
-            float S = 0.f;
-#pragma unroll
-            for (int k = 0; k < 2 * R; k++) S += C[k];
-#pragma unroll
-            for (int j = 0; j < WT; j++) {
-                S += C[j + 2 * R];
-                const float nc = ncrow[j];
-                const float ng = ngrow[j];
-                const float srv = sr[j];
-                float tt = __builtin_fmaf(nc, srv, S);       // S - c*S_R, exact
-                float cov = __builtin_fmaf(ng, srv, tt);     // - (rem/N)*S_R
-                float sc = __builtin_fmaf(cov, ir[j], bias);
-                S -= C[j];
-
-                // ---- argmax over the 64 disparities of this wavefront ----
-                float red = wave_max_to_lane63(sc);
-                float mx = readlane_f(red, 63);
-                unsigned long long hit = __ballot(sc == mx);
-                int idx = hit ? (int)__builtin_ctzll(hit) : 0;
-                float sm = readlane_f(sc, (idx + 63) & 63);
-                float sp = readlane_f(sc, (idx + 1) & 63);
-                float e0 = readlane_f(sc, 0);
-                float e63 = readlane_f(sc, 63);
-                rBest = writelane_f(mx, j, rBest);
-                rIdx = writelane_f(__builtin_bit_cast(float, idx), j, rIdx);
-                rSm = writelane_f(sm, j, rSm);
-                rSp = writelane_f(sp, j, rSp);
-                rE0 = writelane_f(e0, j, rE0);
-                rE63 = writelane_f(e63, j, rE63);
-                if (WANT2) {
-                    int dl = lane - idx;
-                    float sc2 = (dl >= -1 && dl <= 1) ? -INFINITY : sc;
-                    float red2 = wave_max_to_lane63(sc2);
-                    rSec = writelane_f(readlane_f(red2, 63), j, rSec);
-                }
-            }
-            if (lane < WT) {
-                float* res = sRes + ((size_t)(buf * nchunk + chunk) * NFIELD) * WT + lane;
-                res[F_BEST * WT] = rBest;
-                res[F_IDX * WT] = rIdx;
-                res[F_SM * WT] = rSm;
-                res[F_SP * WT] = rSp;
-                res[F_E0 * WT] = rE0;
-                res[F_E63 * WT] = rE63;
-                if (WANT2) res[F_SEC * WT] = rSec;
-            }
-        }
-
-        // ---- publish the prefetched row ----
-        if (have_next) {
-            const int nb = buf ^ 1;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                int i = threadIdx.x + q * nthreads;
-                if (i < LEN) {
-                    sBp[nb * LEN + i] = __builtin_bit_cast(float, nbp[q]);
-                    if (next_score) { sSR[nb * LEN + i] = nsr[q]; sIR[nb * LEN + i] = nir[q]; }
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- one wavefront merges the chunks of this row and writes the outputs ----
-        if (score && chunk == (t % nchunk) && lane < WT) {
-            const int x = x0 + lane;
-            if (x < a.W - R) {
-                const float* res = sRes + (size_t)(buf * nchunk) * NFIELD * WT + lane;
-                float best = -INFINITY, sm = NAN, sp = NAN;
-                int bc = -1, bidx = 0;
-                for (int c = 0; c < nchunk; c++) {
-                    const float* rc = res + (size_t)c * NFIELD * WT;
-                    float v = rc[F_BEST * WT];
-                    if (v > best) { best = v; bc = c; bidx = __builtin_bit_cast(int, rc[F_IDX * WT]); }
-                }
-                const size_t o = (size_t)yout * a.out_pitch + x;
-                if (bc < 0) {
-                    oDisp[o] = (float)MIS_INVALID_DISP;
-                    oPeak[o] = 0.f;
-                    if (oIdisp) oIdisp[o] = (int16_t)MIS_INVALID_DISP;
-                    if (WANT2) oPeak2[o] = -1.f;
-                } else {
-                    const float* rc = res + (size_t)bc * NFIELD * WT;
-                    if (bidx > 0) sm = rc[F_SM * WT];
-                    else if (bc > 0) sm = rc[F_E63 * WT - (ptrdiff_t)NFIELD * WT];
-                    if (bidx < 63) sp = rc[F_SP * WT];
-                    else if (bc + 1 < nchunk) sp = rc[F_E0 * WT + (ptrdiff_t)NFIELD * WT];
-                    float delta = 0.f;
-                    // neighbours that are not valid disparities hold NaN or -inf
-                    if (sm > -INFINITY && sp > -INFINITY) {
-                        float den = 2.f * (sm - 2.f * best + sp);
-                        if (den != 0.f) {
-                            delta = (sm - sp) / den;
-                            delta = fminf(0.5f, fmaxf(-0.5f, delta));
-                        }
-                    }
-                    const int dbest = a.dmin + bc * 64 + bidx;
-                    const float il = gIL[(size_t)yout * P + (x - R)];
-                    oDisp[o] = (float)dbest + delta;
-                    oPeak[o] = best * il;
-                    if (oIdisp) oIdisp[o] = (int16_t)dbest;
-                    if (WANT2) {
-                        float sec = -INFINITY;
-                        for (int c = 0; c < nchunk; c++) {
-                            const float* r2 = res + (size_t)c * NFIELD * WT;
-                            float v;
-                            if (c == bc) v = r2[F_SEC * WT];
-                            else if (c == bc + 1 && bidx == 63) {
-                                // lane 0 of the next chunk is excluded
-                                int i2 = __builtin_bit_cast(int, r2[F_IDX * WT]);
-                                v = (i2 != 0) ? r2[F_BEST * WT] : fmaxf(r2[F_SP * WT], r2[F_SEC * WT]);
-                            } else if (c == bc - 1 && bidx == 0) {
-                                int i2 = __builtin_bit_cast(int, r2[F_IDX * WT]);
-                                v = (i2 != 63) ? r2[F_BEST * WT] : fmaxf(r2[F_SM * WT], r2[F_SEC * WT]);
-                            } else v = r2[F_BEST * WT];
-                            if (v > sec) sec = v;     // NaN and -inf never win
-                        }
-                        oPeak2[o] = (sec > -INFINITY) ? sec * il : -1.f;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fast path (no second-peak output): integer argmax first, exact scores of the winner and its two
-// neighbours afterwards.
+// Integer argmax first, exact scores of the winner and its two neighbours afterwards.
 //
-// Argmax kernel: same lane <-> disparity walk as above, but the per-column reduction over the 64
-// lanes is batched.  Every score is turned into a key (low 6 mantissa bits replaced by 63 - lane,
+// Argmax kernel: lane <-> disparity, and the per-column reduction over the 64 lanes is batched.
+// Every score is turned into a key (low 6 mantissa bits replaced by 63 - lane,
 // so a float maximum also picks the lowest disparity among scores that agree in their upper 26
 // bits); 64 key registers (one per strip column) go through a transposing max network
 // (v_permlane32_swap / v_permlane16_swap, then DPP row and quad steps with write masks) that ends
@@ -562,18 +291,22 @@ struct NccWaveCfg {
     static constexpr int LENP = ((SEG + 7 + 47) / 64) * 64 + 16;   // >= SEG + 7, == 16 (mod 64)
 };
 
-template <int R, int WT, int MW>
+// WANT2: a second key plane per chunk, oKeys2: the best key among the lanes further than one lane
+// from the column's winner (the refinement builds the second-peak output from both planes).  The keys
+// of 16 columns stay in registers until their winners are known, so this variant runs with one
+// wavefront per SIMD less and the short pipeline stages.
+template <int R, int WT, int MW, bool WANT2>
 __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
     NccArgs a,
     const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
     const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr, const float* __restrict__ gRir,
-    float* __restrict__ oKeys)
+    float* __restrict__ oKeys, float* __restrict__ oKeys2)
 {
     static_assert(WT == 64 || WT == 48 || WT == 32, "strip width");
     using Cfg = NccWaveCfg<R, WT>;
     constexpr int WN = 2 * R + 1;
     constexpr int NCP = Cfg::NCP, SEG = Cfg::SEG, LENP = Cfg::LENP;
-    constexpr int GA = MW >= 5 ? 8 : 16, GB = MW >= 5 ? 4 : 8;      // columns per software-pipeline stage
+    constexpr int GA = (MW >= 5 || WANT2) ? 8 : 16, GB = (MW >= 5 || WANT2) ? 4 : 8;      // columns per software-pipeline stage
     __shared__ __attribute__((aligned(16))) float sArr[12 * LENP];   // [3 arrays][4 copies][LENP]
     // Copy c of an array holds element i at i + ((4 - c) & 3): a lane whose run starts at element e
     // reads copy e & 3 from a 16-byte aligned position.  The 16 lanes that one ds_read_b128 cycle
@@ -743,13 +476,15 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
             }
         }
 
-        float red = 0.f;
+        float red = 0.f, red2 = 0.f;
         if (score) {
             float S = 0.f;
 #pragma unroll
             for (int k = 0; k < 2 * R; k++) S += C[k];
             float q[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
-            NccTree tr;
+            float q2[4] = { -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
+            NccTree tr, tr2;
+            float kk[WANT2 ? 16 : 1];                           // keys of the current block of 16 columns
 #pragma unroll
             for (int g = 0; g < NGB; g++) {
                 const int set = g & 1;
@@ -781,13 +516,31 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
                 for (int pq = 0; pq < NP; pq++) sc[pq] = __builtin_elementwise_fma(cov[pq], i2[pq], bias2);
                 static_assert(GB % 4 == 0, "columns are keyed four at a time");
 #pragma unroll
-                for (int pq = 0; pq < NP; pq += 2)
-                    tr.push4((GB * g + 2 * pq) & 15, sc[pq].x, sc[pq].y, sc[pq + 1].x, sc[pq + 1].y, tag);
-                if (((GB * (g + 1)) & 15) == 0) q[(GB * g) >> 4] = tr.q;
+                for (int pq = 0; pq < NP; pq += 2) {
+                    const int jj = (GB * g + 2 * pq) & 15;
+                    if constexpr (WANT2) {
+                        float k0 = sc[pq].x, k1 = sc[pq].y, k2 = sc[pq + 1].x, k3 = sc[pq + 1].y;
+                        tr.push4_keep(jj, k0, k1, k2, k3, tag);
+                        kk[jj] = k0; kk[jj + 1] = k1; kk[jj + 2] = k2; kk[jj + 3] = k3;
+                    } else {
+                        tr.push4(jj, sc[pq].x, sc[pq].y, sc[pq + 1].x, sc[pq + 1].y, tag);
+                    }
+                }
+                if (((GB * (g + 1)) & 15) == 0) {
+                    q[(GB * g) >> 4] = tr.q;
+                    if constexpr (WANT2) {
+                        // the 16 winners are known now: mask the three lanes around each and reduce again
+                        const float qf = ncc_quad_full(tr.q);
+                        const float low = -3.0e38f;
+                        ncc_second_pass16(kk, qf, low, tr2);
+                        q2[(GB * g) >> 4] = tr2.q;
+                    }
+                }
                 ncc_pin(S);
                 __builtin_amdgcn_sched_barrier(0);
             }
             red = ncc_reduce_quads(q[0], q[1], q[2], q[3], lane);
+            if constexpr (WANT2) red2 = ncc_reduce_quads(q2[0], q2[1], q2[2], q2[3], lane);
         }
 
         // the LDS image is single-buffered: every read of this row was issued above, LDS executes a
@@ -801,8 +554,10 @@ __global__ __launch_bounds__(64, MW) void ncc_argmax_kernel(
         // acknowledgement, a full memory round trip per row.
         if (score) {
             const int x = x0 + mycol;
-            if (mycol < WT && x < a.W - R)
+            if (mycol < WT && x < a.W - R) {
                 oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red;
+                if constexpr (WANT2) oKeys2[((size_t)chunk * a.H + yout) * a.out_pitch + x] = red2;
+            }
         }
     }
 }
@@ -830,7 +585,7 @@ __global__ __launch_bounds__(NCC_TAIL_NT) void ncc_tail_kernel(
     NccArgs a, int d0, int nt, int chunk,
     const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
     const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr, const float* __restrict__ gRir,
-    float* __restrict__ oKeys)
+    float* __restrict__ oKeys, float* __restrict__ oKeys2)      // oKeys2 (nullable): second-peak plane, as in the argmax kernel
 {
     constexpr int WN = 2 * R + 1, TW = NCC_TAIL_TW(R), NCOL = TW + 2 * R, RB = NCC_TAIL_RB;
     __shared__ float sC[RB][NCC_TAIL_MAX][NCOL + 2];
@@ -896,8 +651,11 @@ __global__ __launch_bounds__(NCC_TAIL_NT) void ncc_tail_kernel(
             if (t < 2 * R || t >= T || !outcol) continue;
             const int yout = yb0 - R + t - R;
             float best = -3.0e38f;
+            float keyj[NCC_TAIL_MAX];
+            int jb = -9;
 #pragma unroll
             for (int j = 0; j < NCC_TAIL_MAX; j++) {
+                keyj[j] = -3.0e38f;
                 if (j < nt) {
                     float S = 0.f;
 #pragma unroll
@@ -906,10 +664,18 @@ __global__ __launch_bounds__(NCC_TAIL_NT) void ncc_tail_kernel(
                     const float cov = __builtin_fmaf(ng[b], srv[b][j], tt);
                     const float sc = __builtin_fmaf(cov, irv[b][j], 0.f);      // NaN where this disparity is not valid
                     const float key = ncc_make_key(sc, 63u - (uint32_t)(d0 + j - (a.dmin + chunk * 64)));
-                    if (key > best) best = key;                                // NaN never wins
+                    if (key > best) { best = key; jb = j; }                    // NaN never wins
+                    keyj[j] = key;
                 }
             }
             oKeys[((size_t)chunk * a.H + yout) * a.out_pitch + x] = best;
+            if (oKeys2) {                                                      // best key further than one disparity from the winner
+                float second = -3.0e38f;
+#pragma unroll
+                for (int j = 0; j < NCC_TAIL_MAX; j++)
+                    if (j < nt && (j < jb - 1 || j > jb + 1) && keyj[j] > second) second = keyj[j];
+                oKeys2[((size_t)chunk * a.H + yout) * a.out_pitch + x] = second;
+            }
         }
         __syncthreads();
     }
@@ -936,12 +702,20 @@ struct NccRefineCfg {
     static size_t lds_bytes(int nd) { return (size_t)NQ * (LC + right_cols(nd)) * sizeof(uint32_t); }
 };
 
-template <int R>
+// WANT2: the second-peak output (best score further than one disparity from the winner).  Candidates:
+// the winner's chunk contributes its second key plane (lanes further than one lane from its winner),
+// every other chunk its best key -- except a neighbouring chunk whose best lane touches the winner
+// across the chunk boundary (winner in lane 63, neighbour's best in lane 0, or the mirror case): that
+// chunk contributes its second plane, which also leaves out the neighbour's lane 1 (or 62), i.e. the
+// disparity two away from the winner, whose exact score is then computed here like the winner's.
+// Key values carry 26 bits of the score (relative error below 8e-6).
+template <int R, bool WANT2>
 __global__ __launch_bounds__(512) void ncc_refine_kernel(
     NccArgs a, const uint32_t* __restrict__ VL, const uint32_t* __restrict__ VR,
     const float* __restrict__ gNegc, const float* __restrict__ gNegg, const float* __restrict__ gIL,
     const float* __restrict__ gRsr, const float* __restrict__ gRir, const float* __restrict__ gKeys, int nchunk,
-    float* __restrict__ oDisp, float* __restrict__ oPeak, int16_t* __restrict__ oIdisp)
+    float* __restrict__ oDisp, float* __restrict__ oPeak, int16_t* __restrict__ oIdisp,
+    const float* __restrict__ gKeys2, float* __restrict__ oPeak2)
 {
     using Cfg = NccRefineCfg<R>;
     constexpr int NQ = Cfg::NQ, LC = Cfg::LC;
@@ -960,6 +734,8 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     const size_t o = (size_t)y * a.out_pitch + x;
     // merge the chunk keys: lowest chunk wins among equal (truncated) scores
     int ds = MIS_INVALID_DISP;
+    float sec = -1.0e30f;                          // WANT2: best second-peak candidate so far (argmax-kernel scale)
+    int xd = 0;                                    // WANT2: +2 / -2 when the disparity two away needs its exact score
     if (inside) {
         float best = -1.0e30f;                     // below any score, above the bias of masked lanes
         const size_t plane = (size_t)a.H * a.out_pitch;
@@ -976,7 +752,20 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
             }
         }
         if (oIdisp) oIdisp[o] = (int16_t)ds;
-        if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; }
+        if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; if (WANT2) oPeak2[o] = -1.f; }
+        if (WANT2 && ds != MIS_INVALID_DISP) {
+            const int bc = (ds - a.dmin) >> 6, lw = (ds - a.dmin) & 63;
+            for (int c = 0; c < nchunk; c++) {
+                const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * plane + o]);
+                const int l1 = 63 - (int)(kb & 63u);
+                bool second_plane = (c == bc);
+                if (c == bc + 1 && lw == 63 && l1 == 0) { second_plane = true; xd = 2; }
+                if (c == bc - 1 && lw == 0 && l1 == 63) { second_plane = true; xd = -2; }
+                const uint32_t vb = second_plane ? __builtin_bit_cast(uint32_t, gKeys2[(size_t)c * plane + o]) : kb;
+                const float v = __builtin_bit_cast(float, vb & 0xFFFFFFC0u);
+                if (v > sec) sec = v;
+            }
+        }
     }
     const bool valid = inside && ds != MIS_INVALID_DISP;
 
@@ -1079,6 +868,39 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     }
     oDisp[o] = (float)ds + delta;
     oPeak[o] = s0 * il;
+    if constexpr (WANT2) {
+        // exact score of the disparity two away from the winner, where a chunk boundary hid it (rare: the
+        // extra pass runs only in wavefronts that hold such a pixel)
+        const int d2 = ds + xd;
+        const bool need = xd != 0 && d2 >= a.dmin && d2 <= a.dmax;
+        if (__any(need)) {
+            const int u2 = need ? x - d2 : u;
+            int Sx = 0;
+            const uint32_t* px = tR + (u2 - R - cbase);
+#pragma unroll
+            for (int qi = 0; qi < NQ; qi++) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int row = 4 * (qb + qi) + k;
+                    if (row >= y - R && row <= y + R) m |= 0xFFu << (8 * k);
+                }
+                if (m == 0) continue;
+                const uint32_t* plq = pl + qi * LC;
+                const uint32_t* pxq = px + qi * NC;
+#pragma unroll
+                for (int i = 0; i <= 2 * R; i++) Sx = __builtin_amdgcn_sdot4((int)(plq[i] & m), (int)pxq[i], Sx, false);
+            }
+            if (need && u2 >= 0 && u2 < a.W) {
+                const float srx = gRsr[(size_t)y * P + u2], irx = gRir[(size_t)y * P + u2];
+                const float tt = __builtin_fmaf(nc, srx, (float)Sx);
+                const float cov = __builtin_fmaf(ng, srx, tt);
+                const float sx = __builtin_fmaf(cov, irx, 0.f);              // NaN where the window does not fit
+                if (sx > sec) sec = sx;
+            }
+        }
+        oPeak2[o] = (sec > -1.0e30f) ? sec * il : -1.f;
+    }
 }
 
 // fills the frame border (pixels whose window does not fit) of rows [row0,row1)
@@ -1183,28 +1005,8 @@ static int ncc_prepare(mis_ctx* ctx, int window, bool use_side, int need_lo, int
     return MIS_OK;
 }
 
-template <int R, int WT>
-static int ncc_launch(mis_ctx* ctx, const NccArgs& a, float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
-{
-    const int nstrips = (a.W - 2 * R + WT - 1) / WT;
-    const int nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
-    const int LEN = WT + 2 * R + a.nchunk * 64;
-    const size_t shmem = (size_t)(6 * LEN + 2 * a.nchunk * NFIELD * WT) * 4;
-    dim3 grid(nstrips, nbands), block(a.nchunk * 64);
-    const NccWs* w = ctx->ncc;
-    auto kern = d_peak2 ? ncc_main_kernel<R, WT, true> : ncc_main_kernel<R, WT, false>;
-    if (shmem > 64 * 1024)
-        MIS_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    mis_prof_mark(ctx);                            // tables done
-    hipLaunchKernelGGL(kern, grid, block, shmem, ctx->stream, a, w->Lpack, w->negc, w->negg, w->iL,
-                       w->Rpack, w->Rsr, w->Rir, d_disp, d_peak, d_idisp, d_peak2);
-    mis_prof_mark(ctx);
-    MIS_HIP(ctx, hipGetLastError());
-    return MIS_OK;
-}
-
-template <int R, int WT, int MW>
-static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
+template <int R, int WT, int MW, bool WANT2>
+static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
 {
     NccWs* w = ctx->ncc;
     // a short remainder of the range (nd % 64 disparities) goes to the tail kernel instead of a
@@ -1213,9 +1015,11 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     const int rem = nd % 64, nfull = nd / 64;
     const bool tail = (rem > 0 && rem <= NCC_TAIL_MAX && nfull >= 1);
     const int nplanes = a.nchunk;                    // key planes the refinement merges
-    const size_t keys_bytes = (size_t)nplanes * a.H * a.W * sizeof(float);
+    const size_t plane_px = (size_t)a.H * a.W;
+    const size_t keys_bytes = (size_t)nplanes * plane_px * sizeof(float) * (WANT2 ? 2 : 1);
     int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, keys_bytes);
     if (rc) return rc;
+    float* keys2 = WANT2 ? w->keys + (size_t)nplanes * plane_px : nullptr;      // second-peak planes behind the first ones
     a.nstrips = (a.W - 2 * R + WT - 1) / WT;
     a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
     if (tail) a.nchunk = nfull;
@@ -1230,20 +1034,21 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
         ta.band_rows = 64;
         ta.nbands = (a.row1 - a.row0 + ta.band_rows - 1) / ta.band_rows;
         hipLaunchKernelGGL(ncc_tail_kernel<R>, dim3((a.W - 2 * R + NCC_TAIL_TW(R) - 1) / NCC_TAIL_TW(R), ta.nbands), dim3(NCC_TAIL_NT), 0, w->side,
-                           ta, a.dmin + nfull * 64, rem, nfull, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+                           ta, a.dmin + nfull * 64, rem, nfull, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys, keys2);
     }
-    hipLaunchKernelGGL((ncc_argmax_kernel<R, WT, MW>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
-                       a, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+    hipLaunchKernelGGL((ncc_argmax_kernel<R, WT, MW, WANT2>), dim3((unsigned)(a.nstrips * a.nbands * a.nchunk)), dim3(64), 0, ctx->stream,
+                       a, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys, keys2);
     mis_prof_mark(ctx);
     rc = ncc_join(ctx, w);                         // vertical packs, border, tail
     if (rc) return rc;
     {
         const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
         if (lds > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ncc_refine_kernel<R>, dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, WANT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ncc_refine_kernel<R, WANT2>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
                            lds, ctx->stream,
-                           a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nplanes, d_disp, d_peak, d_idisp);
+                           a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nplanes, d_disp, d_peak, d_idisp,
+                           keys2, d_peak2);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
@@ -1264,8 +1069,8 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     if (nrows == 0) return MIS_OK;
 
     mis_prof_mark(ctx);
-    // 8-bit pairs without the second-peak output take the fast path, which runs its small kernels on a second stream
-    const bool fast = (ctx->dtype == MIS_U8 && !d_peak2 && W >= window && H >= window);
+    // the 8-bit path runs its small kernels on a second stream
+    const bool fast = (ctx->dtype == MIS_U8 && W >= window && H >= window);
     if (fast && !ctx->ncc) ctx->ncc = new NccWs();
     {   // frame border
         hipStream_t sb = ctx->stream;
@@ -1279,7 +1084,6 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     }
     if (W < window || H < window) { mis_prof_mark(ctx); mis_prof_mark(ctx); mis_prof_mark(ctx); return MIS_OK; }
     if (ctx->dtype == MIS_U16) {
-        if (d_peak2) return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: the second-peak output is only available for 8-bit rasters");
         NccArgs a;
         a.W = W; a.H = H; a.pitch = 0;
         a.dmin = dmin; a.dmax = dmax;
@@ -1293,7 +1097,7 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
             const long long strips = (W - 2 * r + 31) / 32, bands256 = (a.row1 - a.row0 + 255) / 256;
             a.band_rows = strips * bands256 * a.nchunk >= 6 * 3072 ? 256 : 128;
         }
-        return mis_ncc16_run(ctx, window, a, d_disp, d_peak, d_idisp);
+        return mis_ncc16_run(ctx, window, a, d_disp, d_peak, d_idisp, d_peak2);
     }
     if (ctx->dtype != MIS_U8)
         return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: 8-bit and 16-bit rasters only");
@@ -1328,20 +1132,16 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     // few, uneven rounds of wavefronts: 12.5 and 12.35), as long as the grid still has several rounds of
     // wavefronts for the 5120 wave slots of the chip.
     a.band_rows = 128;
-    if (!d_peak2) {
+    {
         const long long strips = (W - 2 * r + 31) / 32, bands256 = (a.row1 - a.row0 + 255) / 256;
         if (strips * bands256 * (nd / 64 > 0 ? nd / 64 : 1) >= 6 * 5120) a.band_rows = 256;
     }
-
-    // a workgroup holds at most 16 wavefronts: wider ranges would need a merge across
-    // workgroups, which this build does not have
-    if (total_chunks > 16 && d_peak2)
-        return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: the second-peak output supports at most 1024 disparities");
     a.nchunk = total_chunks;
-#define NCC_WT(RR) 32
+    // wavefronts per SIMD the register budget is set for: 5 up to 23 x 23 windows, 4 beyond; the
+    // second-peak variant keeps 16 more keys in registers: 4 wavefronts for every window
 #define NCC_MW(RR) ((RR) <= 11 ? 5 : 4)
-#define NCC_CASE(RR) case RR: rc = d_peak2 ? ncc_launch<RR, 32>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
-                               : ncc_launch_fast<RR, NCC_WT(RR), NCC_MW(RR)>(ctx, a, d_disp, d_peak, d_idisp); break;
+#define NCC_CASE(RR) case RR: rc = d_peak2 ? ncc_launch_fast<RR, 32, 4, true>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
+                               : ncc_launch_fast<RR, 32, NCC_MW(RR), false>(ctx, a, d_disp, d_peak, d_idisp, nullptr); break;
     switch (r) {
         NCC_CASE(1) NCC_CASE(2) NCC_CASE(3) NCC_CASE(4) NCC_CASE(5) NCC_CASE(6) NCC_CASE(7) NCC_CASE(8)
         NCC_CASE(9) NCC_CASE(10) NCC_CASE(11) NCC_CASE(12) NCC_CASE(13) NCC_CASE(14) NCC_CASE(15)

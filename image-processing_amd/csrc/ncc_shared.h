@@ -16,7 +16,7 @@ struct NccArgs {
 };
 
 // 16-bit pairs (ncc16_kernels.hip); a: geometry filled in by the caller except pitch/nstrips/nbands
-int mis_ncc16_run(mis_ctx* ctx, int window, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp);
+int mis_ncc16_run(mis_ctx* ctx, int window, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2);
 
 // key of a score for the batched argmax: upper 26 bits of the float, 63 - lane below
 __device__ __forceinline__ float ncc_make_key(float sc, uint32_t tag)
@@ -85,6 +85,41 @@ __device__ __forceinline__ float ncc_quad4(float s0, float s1, float s2, float s
     return p;
 }
 
+// Same, and the four keys are handed back (the second-peak pass masks and reduces them again).
+__device__ __forceinline__ float ncc_quad4_keep(float& s0, float& s1, float& s2, float& s3, uint32_t tag)
+{
+    float o0, o1, p;
+    asm volatile("v_and_or_b32 %3, %3, %7, %8\n\t"
+                 "v_and_or_b32 %4, %4, %7, %8\n\t"
+                 "v_and_or_b32 %5, %5, %7, %8\n\t"
+                 "v_and_or_b32 %6, %6, %7, %8\n\t"
+                 "v_max_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_max_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_max_f32_dpp %2, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "s_nop 0\n\t"
+                 "v_max_f32_dpp %2, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(o0), "=&v"(o1), "=&v"(p), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3)
+                 : "s"(0xFFFFFFC0u), "v"(tag));
+    return p;
+}
+// The two DPP levels on four ready-made keys.
+__device__ __forceinline__ float ncc_quad4_keys(float k0, float k1, float k2, float k3)
+{
+    float o0, o1, p;
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_max_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_max_f32_dpp %2, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "s_nop 0\n\t"
+                 "v_max_f32_dpp %2, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(o0), "=&v"(o1), "=&v"(p) : "v"(k0), "v"(k1), "v"(k2), "v"(k3));
+    return p;
+}
+
 // Keys of 16 columns (lane = candidate) -> one register in which every 4-lane bank holds the 4
 // partial maxima of one column.  Columns are pushed one at a time (jj = 0..15, a compile-time
 // constant after unrolling); pairs are merged as soon as both halves exist, so at most five
@@ -107,13 +142,54 @@ struct NccTree {
     // four columns at once (jj = 0, 4, 8, 12), from their scores
     __device__ __forceinline__ void push4(int jj, float s0, float s1, float s2, float s3, uint32_t tag)
     {
-        const float m2 = ncc_quad4(s0, s1, s2, s3, tag);
+        push_m2(jj, ncc_quad4(s0, s1, s2, s3, tag));
+    }
+    // same; the scores are replaced by their keys
+    __device__ __forceinline__ void push4_keep(int jj, float& s0, float& s1, float& s2, float& s3, uint32_t tag)
+    {
+        push_m2(jj, ncc_quad4_keep(s0, s1, s2, s3, tag));
+    }
+    // four columns at once from ready-made keys
+    __device__ __forceinline__ void push4_keys(int jj, float k0, float k1, float k2, float k3)
+    {
+        push_m2(jj, ncc_quad4_keys(k0, k1, k2, k3));
+    }
+    __device__ __forceinline__ void push_m2(int jj, float m2)
+    {
         if ((jj & 4) == 0) { t2 = m2; return; }
         const float m3 = ncc_merge32(t2, m2);
         if ((jj & 8) == 0) { t3 = m3; return; }
         q = ncc_merge16(t3, m3);
     }
 };
+
+// ---- second peak: the best key of a column among the lanes further than one lane from its winner ----
+// In a finished 16-column register (NccTree::q) column jj occupies the four lanes 4 * NCC_BANK16[jj] ..
+// + 3, each holding a partial maximum (the network's fixed permutation; ncc_reduce_quads later picks
+// one lane per column).  ncc_quad_full makes all four lanes hold the column maximum.
+__device__ constexpr int NCC_BANK16[16] = { 0, 2, 1, 3, 8, 10, 9, 11, 4, 6, 5, 7, 12, 14, 13, 15 };
+__device__ __forceinline__ float ncc_quad_full(float q)
+{
+    float t = q;
+    NCC_DPP_MAX(t, q, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    float u = t;
+    NCC_DPP_MAX(u, t, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    return u;
+}
+// key with the lanes winner-1 .. winner+1 replaced by `low`; qfull: ncc_quad_full of the register that
+// holds column jj (a compile-time constant).  The winner's key is read into a scalar register, the
+// three-lane mask is scalar arithmetic, and one v_cndmask per column applies it.
+template <int JJ>
+__device__ __forceinline__ float ncc_mask_near_winner(float key, float qfull, float low)
+{
+    const uint32_t kw = (uint32_t)__builtin_amdgcn_readlane(__builtin_bit_cast(int, qfull), 4 * NCC_BANK16[JJ]);
+    const uint32_t lw = ~kw & 63u;                                   // winner's lane: the tag is 63 - lane
+    const unsigned long long m = lw == 0 ? 3ull : (7ull << (lw - 1));
+    float out;
+    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(key), "v"(low), "s"(m));
+    return out;
+}
+
 
 // four such registers -> one register with 64 column maxima (one per lane)
 __device__ __forceinline__ float ncc_reduce_quads(float q0, float q1, float q2, float q3, int lane)
@@ -131,3 +207,16 @@ __device__ __forceinline__ float ncc_reduce_quads(float q0, float q1, float q2, 
     return (lane & 1) ? u1 : u0;
 }
 
+
+// second pass over a block of 16 columns: keys kk[0..15], qfull = ncc_quad_full of their finished register
+__device__ __forceinline__ void ncc_second_pass16(const float* kk, float qfull, float low, NccTree& tr2)
+{
+    tr2.push4_keys(0, ncc_mask_near_winner<0>(kk[0], qfull, low), ncc_mask_near_winner<1>(kk[1], qfull, low),
+                   ncc_mask_near_winner<2>(kk[2], qfull, low), ncc_mask_near_winner<3>(kk[3], qfull, low));
+    tr2.push4_keys(4, ncc_mask_near_winner<4>(kk[4], qfull, low), ncc_mask_near_winner<5>(kk[5], qfull, low),
+                   ncc_mask_near_winner<6>(kk[6], qfull, low), ncc_mask_near_winner<7>(kk[7], qfull, low));
+    tr2.push4_keys(8, ncc_mask_near_winner<8>(kk[8], qfull, low), ncc_mask_near_winner<9>(kk[9], qfull, low),
+                   ncc_mask_near_winner<10>(kk[10], qfull, low), ncc_mask_near_winner<11>(kk[11], qfull, low));
+    tr2.push4_keys(12, ncc_mask_near_winner<12>(kk[12], qfull, low), ncc_mask_near_winner<13>(kk[13], qfull, low),
+                   ncc_mask_near_winner<14>(kk[14], qfull, low), ncc_mask_near_winner<15>(kk[15], qfull, low));
+}

@@ -39,6 +39,38 @@ def test_peak2(ctx):
     _run(ctx, left, right, 11, -70, 70, peak2=True)
 
 
+@pytest.mark.parametrize("dtype,window,dmin,dmax,shape,shift", [
+    (np.uint8, 21, -256, 256, (70, 900), 63),       # 8 chunks + the one-disparity tail; winner in the last lane of a chunk
+    (np.uint8, 21, -256, 256, (70, 900), -192),     # winner in lane 0 of a chunk: the neighbour across the boundary is excluded
+    (np.uint8, 9, -100, 27, (64, 333), -37),        # two chunks: winner in lane 63 of the first
+    (np.uint8, 7, 0, 67, (50, 260), 62),            # one chunk and a four-disparity tail, winner next to the boundary
+    (np.uint8, 7, 0, 67, (50, 260), 65),            # winner inside the tail
+    (np.uint8, 31, -70, 70, (70, 256), 40),         # 31 x 31 window (fewer wavefronts per SIMD)
+    (np.uint8, 5, -1, 1, (40, 90), 0),              # three disparities: nothing is further than one from the winner
+    (np.uint16, 31, -512, 512, (70, 1500), 333),    # 1025 disparities, 17 chunks (config[4]'s search)
+    (np.uint16, 15, -64, 64, (96, 300), -1),        # winner in lane 63 of chunk 0
+    (np.uint16, 11, -64, 63, (60, 300), 0),         # winner in lane 0 of chunk 1
+])
+def test_peak2_chunk_boundaries(ctx, dtype, window, dmin, dmax, shape, shift):
+    """Second peak (best score further than one disparity from the winner) on 8- and 16-bit pairs:
+    winners at chunk boundaries, where the excluded neighbour lives in another wavefront's chunk or in
+    the tail plane, and ranges of up to 1025 disparities."""
+    left = _texture16(shape[0], shape[1], 55 + window) if dtype == np.uint16 else synth.texture(shape[0], shape[1], 55 + window)
+    right = synth.shift_right_image(left, shift, fill_seed=56)
+    st = _run(ctx, left, right, window, dmin, dmax, peak2=True)
+    assert st["valid"] > 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_peak2_random(ctx, seed):
+    window, h, w, dmin, dmax, dtype, shift = _random_case(3000 + seed)
+    left = _texture16(h, w, seed) if dtype == np.uint16 else synth.texture(h, w, seed)
+    # piecewise disparities: winners land in every lane, repeated content gives real second peaks
+    dmap = synth.planar_disparity(h, w, max(dmin, -60), min(dmax, 60), 16, seed + 7)
+    right = synth.shift_right_image(left, dmap, fill_seed=seed + 500)
+    _run(ctx, left, right, window, dmin, dmax, peak2=True)
+
+
 def test_piecewise_disparity_with_noise(ctx):
     left, right, p = synth.config_pair(2, h=120, w=700)
     _run(ctx, left, right, p["window"], -130, 130)
@@ -126,13 +158,6 @@ def test_u16_wide_search_many_chunks(ctx):
     left = _texture16(70, 1500, 8)
     right = synth.shift_right_image(left, 333, fill_seed=4)
     _run(ctx, left, right, 31, -512, 512)
-
-
-def test_u16_second_peak_is_refused(ctx):
-    left = _texture16(40, 100, 1)
-    ctx.upload_pair(left, left)
-    with pytest.raises(Exception):
-        ctx.ncc_dense(7, -4, 4, want_peak2=True)
 
 
 def _random_case(seed):
