@@ -2,8 +2,10 @@
 //
 // Replaces findOffset + runFFT (image3.cpp:318-335, 346-517), CalcFFT of image-cross-cor.cpp
 // (104-176) and CalcFFT of image-fft.cpp (45-105).  Stages per tile of w x h pixels (N = w*h):
-//   1 load both tiles (zero outside the bounding box), forward row FFTs              xc_rows_fwd
-//   2 forward column FFTs, spectrum product A*conj(B), inverse column FFT, fused      xc_cols
+//   1 load both tiles (zero outside the bounding box) as ONE complex raster a + i b,
+//     forward row FFTs                                                               xc_rows_fwd
+//   2 forward column FFTs, A*conj(B) from the joint spectrum, inverse column FFT,     xc_cols
+//     fused
 //   3 inverse row FFT, |c|, tile min / max                                           xc_rows_inv_abs
 //   4 min-max normalisation to [0,1] and the row pass of the 151-tap Gaussian         xc_norm_rowblur
 //   5 column pass, difference of Gaussians, first maximum                             xc_colblur_argmax
@@ -31,6 +33,7 @@ struct XcorrWs {
     void* buf = nullptr; size_t buf_bytes = 0;      // spectra / surfaces of one batch of tiles
     void* meta = nullptr; size_t meta_bytes = 0;    // per-tile min/max, argmax keys, rects
     const float* last_surface = nullptr;            // normalised surfaces of the last batch (inspection)
+    const float* last_abs = nullptr;                // |c| surfaces of the last batch (before normalisation)
 };
 
 void mis_xcorr_release(mis_ctx* ctx)
@@ -100,8 +103,11 @@ static int ensure_ws(mis_ctx* ctx)
 // (every kernel is launched with exactly its __launch_bounds__): blockDim.x is a load from the
 // dispatch packet, a memory round trip the compiler repeats in every pass.
 // ---------------------------------------------------------------------------------------------
+// (fused multiply-adds are allowed in the transforms: FFTW's own codelets use them where the
+// machine has them, and no particular rounding of the spectrum is part of the reference's behaviour)
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
+#pragma clang fp contract(fast)
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
@@ -267,84 +273,113 @@ __device__ __forceinline__ float load_px(const void* img, int dtype, size_t stri
     return ((const float*)row)[x];
 }
 
-// Pixels of a tile's rows -> LDS as complex values, U loads in flight per thread: coordinates are
-// clamped into the raster so that every load is legal and unconditional, pixels outside the bbox or
-// the raster are replaced by 0 afterwards.  w = 2^logw.
+// Pixels of the rows of a tile pair -> LDS as complex values, image 1 in the real part and image 2 in
+// the imaginary part (both inputs are real, so ONE complex transform carries both spectra: with
+// Z = FFT(a + i b), A[k] = (Z[k] + conj(Z[-k])) / 2 and B[k] = (Z[k] - conj(Z[-k])) / (2i)).
+// U pixel pairs in flight per thread: coordinates are clamped into the raster so that every load is
+// legal and unconditional, pixels outside the bbox or the raster are replaced by 0 afterwards.  w = 2^logw.
 template <typename T, int NT, int U, bool PAD>
-__device__ __forceinline__ void stage_pixels(float2* x, const void* img, const XcImage& im, const mis_rect bb,
+__device__ __forceinline__ void stage_pixels(float2* x, const XcImage& im, const mis_rect b1, const mis_rect b2,
                                              int row0, int w, int logw, int n)
 {
     for (int base = 0; base < n; base += NT * U) {
-        float f[U];
-        bool ok[U];
+        float f[U], g[U];
+        bool ok1[U], ok2[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = base + (int)threadIdx.x + NT * u;
             const int ry = row0 + (i >> logw), rx = i & (w - 1);
-            const int sx = bb.minx + rx, sy = bb.miny + ry;
-            ok[u] = rx < bb.width && ry < bb.height && sx >= 0 && sx < im.iw && sy >= 0 && sy < im.ih;
-            const int cx = min(max(sx, 0), im.iw - 1), cy = min(max(sy, 0), im.ih - 1);
-            f[u] = (float)((const T*)((const unsigned char*)img + (size_t)cy * im.stride))[cx];
+            {
+                const int sx = b1.minx + rx, sy = b1.miny + ry;
+                ok1[u] = rx < b1.width && ry < b1.height && sx >= 0 && sx < im.iw && sy >= 0 && sy < im.ih;
+                const int cx = min(max(sx, 0), im.iw - 1), cy = min(max(sy, 0), im.ih - 1);
+                f[u] = (float)((const T*)((const unsigned char*)im.img[0] + (size_t)cy * im.stride))[cx];
+            }
+            {
+                const int sx = b2.minx + rx, sy = b2.miny + ry;
+                ok2[u] = rx < b2.width && ry < b2.height && sx >= 0 && sx < im.iw && sy >= 0 && sy < im.ih;
+                const int cx = min(max(sx, 0), im.iw - 1), cy = min(max(sy, 0), im.ih - 1);
+                g[u] = (float)((const T*)((const unsigned char*)im.img[1] + (size_t)cy * im.stride))[cx];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) asm volatile("" : "+v"(f[u]));
+        for (int u = 0; u < U; u++) asm volatile("" : "+v"(f[u]), "+v"(g[u]));
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = base + (int)threadIdx.x + NT * u;
-            if (i < n) x[xp<PAD>(i)] = make_float2(ok[u] ? f[u] : 0.f, 0.f);
+            if (i < n) x[xp<PAD>(i)] = make_float2(ok1[u] ? f[u] : 0.f, ok2[u] ? g[u] : 0.f);
         }
     }
 }
 
-// stage 1: grid (rows/RB, 2 images, tiles).  RB rows of one tile per workgroup.
-// spec layout: [tile][img][h][w] float2
+// stage 1: grid (rows/RB, tiles).  RB rows of one tile pair per workgroup.
+// spec layout: [tile][h][w] float2 (image 1 + i * image 2, columns in bit-reversed order)
 // PAD: padded LDS layout (xp), chosen by the host whenever the padded array fits.
 template <bool PAD>
 __global__ __launch_bounds__(256) void xc_rows_fwd(XcImage im, const mis_rect* __restrict__ r1,
                                                    const mis_rect* __restrict__ r2, int tile0,
                                                    int w, int h, int logw, int RB,
-                                                   const float2* __restrict__ tw, float2* __restrict__ spec)
+                                                   const float2* __restrict__ tw, float2* __restrict__ spec,
+                                                   unsigned* __restrict__ minmax, unsigned long long* __restrict__ keys)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* x = (float2*)smem_raw;
-    const int t = blockIdx.z, side = blockIdx.y, row0 = blockIdx.x * RB;
-    const mis_rect bb = side ? r2[tile0 + t] : r1[tile0 + t];
-    const void* img = im.img[side];
+    const int t = blockIdx.y, row0 = blockIdx.x * RB;
+    const mis_rect b1 = r1[tile0 + t], b2 = r2[tile0 + t];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // the tile's extrema (and, first band only, its peak key) start over
+        minmax[2 * t] = 0x7F800000u;                // +inf
+        minmax[2 * t + 1] = 0u;
+        if (keys) keys[t] = 0ull;
+    }
     // image3.cpp:322-328: the buffer is zeroed, then the bbox region is read into it
-    if (im.dtype == MIS_U8) stage_pixels<uint8_t, 256, 8, PAD>(x, img, im, bb, row0, w, logw, RB * w);
-    else if (im.dtype == MIS_U16) stage_pixels<uint16_t, 256, 8, PAD>(x, img, im, bb, row0, w, logw, RB * w);
-    else stage_pixels<float, 256, 8, PAD>(x, img, im, bb, row0, w, logw, RB * w);
+    if (im.dtype == MIS_U8) stage_pixels<uint8_t, 256, 4, PAD>(x, im, b1, b2, row0, w, logw, RB * w);
+    else if (im.dtype == MIS_U16) stage_pixels<uint16_t, 256, 4, PAD>(x, im, b1, b2, row0, w, logw, RB * w);
+    else stage_pixels<float, 256, 4, PAD>(x, im, b1, b2, row0, w, logw, RB * w);
     float2* stw = x + (((size_t)xp<PAD>(RB * w) + 1) & ~(size_t)1);   // twiddles in LDS: every butterfly reads one
     stage_contiguous<256, 2>(stw, tw, w / 2);
     __syncthreads();
     fft_dif_fwd<256, PAD>(x, logw, RB, stw);
-    float2* out = spec + ((size_t)(t * 2 + side) * h + row0) * w;
+    float2* out = spec + ((size_t)t * h + row0) * w;
     for (int i = threadIdx.x; i < RB * w; i += 256) out[i] = x[xp<PAD>(i)];
 }
 
-// stage 2: grid (w/CB, tiles).  CB adjacent columns of both spectra of one tile per workgroup.
-// LDS: A[CB][h], B[CB][h] (column-major so that every column is one contiguous sequence).
+// stage 2: grid (w/(2 CB), tiles).  Forward column transforms of the joint spectrum Z, the product
+// A conj(B) of the two spectra it carries, inverse column transforms, fused.
+//   A conj(B) [k] = Im(Z[k] Z[-k]) / 2 + i (|Z[k]|^2 - |Z[-k]|^2) / 4        (-k: both indices negated)
+// so a workgroup needs the columns of frequency kx together with those of -kx.  Column positions are
+// bit-reversed (position p holds kx = rev(p)): an aligned block of CB positions holds the
+// frequencies kxbase + (jr << sh), jr = rev(j), sh = log2(w / CB), kxbase = rev(block index); its
+// partner frequencies -kx lie in the block with kxbase' = 2^sh - kxbase at position j' = CB-1-j
+// (kxbase = 0 is its own partner with j' = rev((CB - jr) mod CB), kxbase = 2^(sh-1) with j' = CB-1-j).
+// A workgroup therefore takes two blocks: {b, 2^sh - b}, or the two self-paired ones {0, 2^(sh-1)}.
+// LDS: X[2 CB][h] (column-major so that every column is one contiguous sequence); rows come out of
+// the forward transform bit-reversed as well: row position r holds ky = rev(r), partner rev(-ky).
 template <bool PAD>
-__global__ __launch_bounds__(512) void xc_cols(int w, int h, int logh, int CB, float scale,
+__global__ __launch_bounds__(512) void xc_cols(int w, int h, int logw, int logh, int CB, float scale2,
                                                const float2* __restrict__ tw, float2* __restrict__ spec)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* A = (float2*)smem_raw;
-    const int nB = CB * h;                          // the second spectrum follows the first in one joint array
-    const int t = blockIdx.y, c0 = blockIdx.x * CB;
-    float2* sa = spec + (size_t)(t * 2) * h * w;
-    float2* sb = sa + (size_t)h * w;
+    const int nB = CB * h;
+    const int t = blockIdx.y, g = blockIdx.x;
+    const int logcb = __ffs(CB) - 1, sh = logw - logcb;                 // sh >= 1: the host keeps CB <= w / 2
+    const int nblk = 1 << sh;
+    const int bq[2] = { g == 0 ? 0 : g, g == 0 ? nblk >> 1 : nblk - g };
+    int c0q[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) c0q[q] = (sh ? (int)(__brev((unsigned)bq[q]) >> (32 - sh)) : 0) << logcb;
+    float2* sa = spec + (size_t)t * h * w;
     if (CB >= 2) {
-        // 16-byte loads (two adjacent columns of a row), four per spectrum in flight per thread
+        // 16-byte loads (two adjacent columns of a row), four per block in flight per thread
         const int hc = CB >> 1, lhc = __ffs(hc) - 1, n4 = hc * h;
         for (int base = 0; base < n4; base += 512 * 4) {
             float4 va[4], vb[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int i = min(base + (int)threadIdx.x + 512 * u, n4 - 1);
-                const size_t o = (size_t)(i >> lhc) * w + c0 + 2 * (i & (hc - 1));
-                va[u] = *(const float4*)(sa + o);
-                vb[u] = *(const float4*)(sb + o);
+                const size_t o = (size_t)(i >> lhc) * w + 2 * (i & (hc - 1));
+                va[u] = *(const float4*)(sa + o + c0q[0]);
+                vb[u] = *(const float4*)(sa + o + c0q[1]);
             }
             pin_loaded(va); pin_loaded(vb);
 #pragma unroll
@@ -359,25 +394,44 @@ __global__ __launch_bounds__(512) void xc_cols(int w, int h, int logh, int CB, f
         }
     } else {
         for (int i = threadIdx.x; i < h; i += 512) {
-            A[xp<PAD>(i)] = sa[(size_t)i * w + c0];
-            A[xp<PAD>(nB + i)] = sb[(size_t)i * w + c0];
+            A[xp<PAD>(i)] = sa[(size_t)i * w + c0q[0]];
+            A[xp<PAD>(nB + i)] = sa[(size_t)i * w + c0q[1]];
         }
     }
     float2* stw = A + (((size_t)xp<PAD>(2 * nB) + 1) & ~(size_t)1);
     stage_contiguous<512, 1>(stw, tw, h / 2);
     __syncthreads();
-    fft_dif_fwd<512, PAD>(A, logh, 2 * CB, stw);       // A and B are adjacent: 2*CB sequences
-    // runFFT divides each spectrum by sqrt(N) (image3.cpp:331-334); product image3.cpp:392-394
-    for (int i = threadIdx.x; i < CB * h; i += 512) {
-        float2 a = A[xp<PAD>(i)], b = A[xp<PAD>(nB + i)];
-        a.x *= scale; a.y *= scale; b.x *= scale; b.y *= scale;
-        A[xp<PAD>(i)] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    fft_dif_fwd<512, PAD>(A, logh, 2 * CB, stw);
+    // Product.  Every pair (k, -k) is handled once, by the thread of its element in the first block
+    // (two different blocks), or of its lower index (a self-paired block): P[-k] = conj(P[k]).
+    // runFFT divides each spectrum by sqrt(N) (image3.cpp:331-334): scale2 = 1 / N; product image3.cpp:392-394.
+    const int ntot = (g == 0 ? 2 : 1) * nB;
+    for (int e = threadIdx.x; e < ntot; e += 512) {
+        const int q = e >= nB ? 1 : 0, ee = e - q * nB;
+        const int j = ee >> logh, r = ee & (h - 1);
+        const int rp = logh ? (int)(__brev((unsigned)((h - (int)(__brev((unsigned)r) >> (32 - logh))) & (h - 1))) >> (32 - logh)) : 0;
+        int qp, jp;
+        if (g != 0) { qp = 1; jp = CB - 1 - j; }
+        else if (q == 1) { qp = 1; jp = CB - 1 - j; }
+        else {
+            qp = 0;
+            const int jr = logcb ? (int)(__brev((unsigned)j) >> (32 - logcb)) : 0;
+            jp = logcb ? (int)(__brev((unsigned)((CB - jr) & (CB - 1))) >> (32 - logcb)) : 0;
+        }
+        const int ep = qp * nB + jp * h + rp;
+        if (g == 0 && ep < e) continue;                      // the partner's thread writes both
+        const float2 zk = A[xp<PAD>(e)], zm = A[xp<PAD>(ep)];
+        const float re = 0.5f * (zk.x * zm.y + zk.y * zm.x) * scale2;
+        const float im = 0.25f * ((zk.x * zk.x + zk.y * zk.y) - (zm.x * zm.x + zm.y * zm.y)) * scale2;
+        A[xp<PAD>(e)] = make_float2(re, im);
+        if (ep != e) A[xp<PAD>(ep)] = make_float2(re, -im);
     }
     __syncthreads();
-    fft_dit_inv<512, PAD>(A, logh, CB, stw);
-    for (int i = threadIdx.x; i < CB * h; i += 512) {
-        const int r = i / CB, c = i % CB;
-        sa[(size_t)r * w + c0 + c] = A[xp<PAD>(c * h + r)];
+    fft_dit_inv<512, PAD>(A, logh, 2 * CB, stw);
+    for (int i = threadIdx.x; i < 2 * CB * h; i += 512) {
+        const int q = i >= nB ? 1 : 0, ii = i - q * nB;
+        const int r = ii / CB, c = ii % CB;
+        sa[(size_t)r * w + c0q[q] + c] = A[xp<PAD>(q * nB + c * h + r)];
     }
 }
 
@@ -428,6 +482,11 @@ __device__ __forceinline__ void tile_commit_key(unsigned long long* keys, int t,
 // stage 3: grid (rows/RB, tiles).  Inverse row transform, divide by sqrt(N) (image3.cpp:401-405),
 // magnitude, tile minimum and maximum (image3.cpp:402-411).  minmax[tile] = {min bits, max bits}
 // of non-negative floats, whose unsigned bit patterns order like the values.
+// The correlation of two real rasters is real: after the inverse column transforms every row's
+// spectrum is Hermitian, so two rows ride through ONE complex inverse transform, z = Q[y1] + i Q[y2],
+// whose real part is row y1 and whose imaginary part is row y2 (the reference's own imaginary parts
+// are rounding noise around 1e-7 of the peak, far below the tolerances of the surface).  RB odd
+// (RB == 1: rows of 2048 and more) keeps one row per transform and takes the complex magnitude.
 template <bool PAD>
 __global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, int RB, float scale,
                                                        const float2* __restrict__ tw,
@@ -437,20 +496,58 @@ __global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, i
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* x = (float2*)smem_raw;
     const int t = blockIdx.y, row0 = blockIdx.x * RB;
-    const float2* in = spec + ((size_t)(t * 2) * h + row0) * w;
-    stage_contiguous<256, 4, PAD>(x, in, RB * w);
-    float2* stw = x + (((size_t)xp<PAD>(RB * w) + 1) & ~(size_t)1);
-    stage_contiguous<256, 2>(stw, tw, w / 2);
-    __syncthreads();
-    fft_dit_inv<256, PAD>(x, logw, RB, stw);
+    const float2* in = spec + ((size_t)t * h + row0) * w;
     float* out = surf + ((size_t)t * h + row0) * w;
     float lo = INFINITY, hi = 0.f;
-    for (int i = threadIdx.x; i < RB * w; i += 256) {
-        const float2 v = x[xp<PAD>(i)];
-        // cabs() of the complex float promoted to double (image3.cpp:407-410)
-        const float m = (float)hypot((double)(v.x * scale), (double)(v.y * scale));
-        out[i] = m;
-        lo = fminf(lo, m); hi = fmaxf(hi, m);
+    if (RB & 1) {
+        stage_contiguous<256, 4, PAD>(x, in, RB * w);
+        float2* stw = x + (((size_t)xp<PAD>(RB * w) + 1) & ~(size_t)1);
+        stage_contiguous<256, 2>(stw, tw, w / 2);
+        __syncthreads();
+        fft_dit_inv<256, PAD>(x, logw, RB, stw);
+        for (int i = threadIdx.x; i < RB * w; i += 256) {
+            const float2 v = x[xp<PAD>(i)];
+            // cabs() of the complex float promoted to double (image3.cpp:407-410)
+            const float m = (float)hypot((double)(v.x * scale), (double)(v.y * scale));
+            out[i] = m;
+            lo = fminf(lo, m); hi = fmaxf(hi, m);
+        }
+    } else {
+        // pairs of rows (2p, 2p+1) -> sequence p; 16-byte loads, four pairs in flight per thread
+        const int half = RB >> 1, n4 = half * (w >> 1);                 // float4 = two complex values
+        const float4* in4 = (const float4*)in;
+        for (int base = 0; base < n4; base += 256 * 4) {
+            float4 va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = min(base + (int)threadIdx.x + 256 * u, n4 - 1);
+                const int p = i / (w >> 1), c = i - p * (w >> 1);
+                va[u] = in4[(size_t)(2 * p) * (w >> 1) + c];
+                vb[u] = in4[(size_t)(2 * p + 1) * (w >> 1) + c];
+            }
+            pin_loaded(va); pin_loaded(vb);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + (int)threadIdx.x + 256 * u;
+                if (i < n4) {
+                    const int p = i / (w >> 1), c = i - p * (w >> 1);
+                    x[xp<PAD>(p * w + 2 * c)] = make_float2(va[u].x - vb[u].y, va[u].y + vb[u].x);
+                    x[xp<PAD>(p * w + 2 * c + 1)] = make_float2(va[u].z - vb[u].w, va[u].w + vb[u].z);
+                }
+            }
+        }
+        float2* stw = x + (((size_t)xp<PAD>(RB * w) + 1) & ~(size_t)1);
+        stage_contiguous<256, 2>(stw, tw, w / 2);
+        __syncthreads();
+        fft_dit_inv<256, PAD>(x, logw, half, stw);
+        for (int i = threadIdx.x; i < half * w; i += 256) {
+            const int p = i >> logw, c = i & (w - 1);
+            const float2 v = x[xp<PAD>(i)];
+            const float m1 = fabsf(v.x * scale), m2 = fabsf(v.y * scale);
+            out[(size_t)(2 * p) * w + c] = m1;
+            out[(size_t)(2 * p + 1) * w + c] = m2;
+            lo = fminf(lo, fminf(m1, m2)); hi = fmaxf(hi, fmaxf(m1, m2));
+        }
     }
     lo = wave_min_f(lo); hi = wave_max_f(hi);
     tile_commit_minmax(minmax, t, lo, hi);
@@ -467,11 +564,13 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-// stage 4: grid (h, tiles): one row per workgroup.  out = (|c| - min) / (max - min)
+// stage 4: grid (h, tiles): one row per workgroup of NT threads (four outputs per thread: NT = w / 4 up to 256, so
+// that no wavefront idles through the filter loop).  out = (|c| - min) / (max - min)
 // (image3.cpp:414-416, evaluated in double and narrowed), columns >= 2*(w/2) and rows >= 2*(h/2)
 // zeroed for the blur input (image3.cpp:471-478); row pass of the Gaussian, taps accumulated left
 // to right with separate multiply and add.
-__global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsigned* __restrict__ minmax,
+template <int NT>
+__global__ __launch_bounds__(NT) void xc_norm_rowblur(int w, int h, const unsigned* __restrict__ minmax,
                                                        const float* __restrict__ gauss,
                                                        float* __restrict__ surf, float* __restrict__ tmp, int pre)
 {
@@ -484,8 +583,8 @@ __global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsig
     const float range = mx - mn;
     float* srow = surf + ((size_t)t * h + y) * w;
     const int w2 = (w / 2) * 2, h2 = (h / 2) * 2;
-    for (int i = threadIdx.x; i < XC_GAUSS_K; i += 256) g[i] = gauss[i];
-    for (int x = threadIdx.x; x < w; x += 256) {
+    for (int i = threadIdx.x; i < XC_GAUSS_K; i += NT) g[i] = gauss[i];
+    for (int x = threadIdx.x; x < w; x += NT) {
         const float m = srow[x];
         // pre: the surface already holds the product of the normalised band surfaces
         const float o = pre ? m : (float)(((double)m - (double)mn) / (double)range);
@@ -494,7 +593,7 @@ __global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsig
     }
     __syncthreads();
     const int kw = (w == 1) ? 1 : XC_GAUSS_K, rx = kw / 2;
-    for (int i = threadIdx.x; i < ((w + 163) & ~3); i += 256) {
+    for (int i = threadIdx.x; i < ((w + 163) & ~3); i += NT) {
         float v = 0.f;
         if (i < w + kw - 1) {
             const int sx = reflect101(i - rx, w);
@@ -505,13 +604,13 @@ __global__ __launch_bounds__(256) void xc_norm_rowblur(int w, int h, const unsig
     __syncthreads();
     float* trow = tmp + ((size_t)t * h + y) * w;
     if (kw == 1) {
-        for (int x = threadIdx.x; x < w; x += 256) trow[x] = prow[x];
+        for (int x = threadIdx.x; x < w; x += NT) trow[x] = prow[x];
         return;
     }
     // four adjacent outputs per thread: the taps slide through registers, so every padded sample and
     // every coefficient is read from LDS once per four outputs (16-byte reads); each output still
     // accumulates its taps left to right with separate multiply and add
-    for (int x0 = 4 * threadIdx.x; x0 < w; x0 += 4 * 256) {
+    for (int x0 = 4 * threadIdx.x; x0 < w; x0 += 4 * NT) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         float4 v = *(const float4*)(prow + x0);
 #pragma unroll 2
@@ -1021,9 +1120,9 @@ static int make_plan(mis_ctx* ctx, int w, int h, XcPlan* p)
     p->logw = ilog2(w); p->logh = ilog2(h);
     p->RBw = w >= 2048 ? 1 : 2048 / w;          // rows per workgroup: 2048 complex values in LDS
     if (p->RBw > h) p->RBw = h;
-    p->CB = h >= 4096 ? 1 : 4096 / h;           // columns per workgroup: 2 x 4096 complex values
+    p->CB = h >= 4096 ? 1 : 4096 / h;           // columns per block, two blocks per workgroup: 2 x 4096 complex values
     if (p->CB > 16) p->CB = 16;
-    if (p->CB > w) p->CB = w;
+    if (p->CB > w / 2) p->CB = w / 2;           // a workgroup takes two blocks of columns (a frequency block and its negative)
     return MIS_OK;
 }
 
@@ -1039,8 +1138,8 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
     int rc = get_twiddle(ctx, w, &tww); if (rc) return rc;
     rc = get_twiddle(ctx, h, &twh); if (rc) return rc;
 
-    float2* spec = (float2*)ws->buf;                                   // [nt][2][h][w]
-    float* surf = (float*)((char*)ws->buf + (size_t)nt * 2 * N * sizeof(float2));   // [nt][h][w]
+    float2* spec = (float2*)ws->buf;                                   // [nt][h][w]: joint spectrum of the tile pair
+    float* surf = (float*)((char*)ws->buf + (size_t)nt * N * sizeof(float2));   // [nt][h][w]
     float* tmp = surf + (size_t)nt * N;                                // [nt][h][w]
     const int nbands = 1 + (int)ctx->band_img[0].size();
     float* prod = tmp + (size_t)nt * N;                                // [nt][h][w], only with several bands
@@ -1051,14 +1150,13 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
     const float scale = (float)(1.0 / sqrt((double)N));
     size_t sh_rows = 0; bool pad_rows = false;      // LDS bytes and layout of the two row kernels
     ws->last_surface = fsurf;
+    ws->last_abs = surf;
 
-    hipLaunchKernelGGL(xc_init_meta, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax, keys);
     for (int band = 0; band < nbands; band++) {
         XcImage im;
         im.img[0] = band ? ctx->band_img[0][band - 1] : ctx->img[0];
         im.img[1] = band ? ctx->band_img[1][band - 1] : ctx->img[1];
         im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
-        if (band) hipLaunchKernelGGL(xc_reset_minmax, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax);
         {
             // padded LDS layout whenever it fits (it does for every tile size but the largest)
             const size_t nx = (size_t)p.RBw * w, nxp = ((nx + nx / 8 + 1) & ~(size_t)1);
@@ -1071,8 +1169,8 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
                 MIS_HIP(ctx, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_rows));
                 MIS_HIP(ctx, hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_rows));
             }
-            hipLaunchKernelGGL(kf, dim3(h / p.RBw, 2, nt), dim3(256), sh_rows, s, im, d_r1, d_r2, tile0,
-                               w, h, p.logw, p.RBw, tww, spec);
+            hipLaunchKernelGGL(kf, dim3(h / p.RBw, nt), dim3(256), sh_rows, s, im, d_r1, d_r2, tile0,
+                               w, h, p.logw, p.RBw, tww, spec, minmax, band == 0 ? keys : (unsigned long long*)nullptr);
         }
         {
             const size_t nx = (size_t)2 * p.CB * h, nxp = ((nx + nx / 8 + 1) & ~(size_t)1);
@@ -1081,7 +1179,7 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
             auto kc = pad ? xc_cols<true> : xc_cols<false>;
             if (sh > 64 * 1024)
                 MIS_HIP(ctx, hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            hipLaunchKernelGGL(kc, dim3(w / p.CB, nt), dim3(512), sh, s, w, h, p.logh, p.CB, scale, twh, spec);
+            hipLaunchKernelGGL(kc, dim3(w / (2 * p.CB), nt), dim3(512), sh, s, w, h, p.logw, p.logh, p.CB, scale * scale, twh, spec);
         }
         {
             auto ki = pad_rows ? xc_rows_inv_abs<true> : xc_rows_inv_abs<false>;
@@ -1094,9 +1192,15 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
     {
         const size_t sh = (size_t)(152 + 2 * w + 168) * sizeof(float);
-        if (sh > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
+        if (w >= 1024 || (w & 3)) {
+            if (sh > 64 * 1024)
+                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            hipLaunchKernelGGL(xc_norm_rowblur<256>, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
+        } else if (w >= 512) {
+            hipLaunchKernelGGL(xc_norm_rowblur<128>, dim3(h, nt), dim3(128), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
+        } else {
+            hipLaunchKernelGGL(xc_norm_rowblur<64>, dim3(h, nt), dim3(64), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
+        }
     }
     hipLaunchKernelGGL(xc_colblur_argmax, dim3((w + 63) / 64, (h + XC_RB5 - 1) / XC_RB5, nt), dim3(256), 0, s,
                        w, h, ws->gauss, fsurf, tmp, dog_dbg, keys);
@@ -1127,6 +1231,7 @@ static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1
     hipStream_t s = ctx->stream;
     const float scale = (float)(1.0 / sqrt((double)N));
     ws->last_surface = fsurf;
+    ws->last_abs = surf;
     hipLaunchKernelGGL(xc_init_meta, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax, keys);
     const dim3 tgrid((w + 31) / 32, (h + 31) / 32, 1), tgridT((h + 31) / 32, (w + 31) / 32, 1);
     for (int band = 0; band < nbands; band++) {
@@ -1150,9 +1255,15 @@ static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
     {
         const size_t sh = (size_t)(152 + 2 * w + 168) * sizeof(float);
-        if (sh > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(xc_norm_rowblur, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
+        if (w >= 1024 || (w & 3)) {
+            if (sh > 64 * 1024)
+                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            hipLaunchKernelGGL(xc_norm_rowblur<256>, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
+        } else if (w >= 512) {
+            hipLaunchKernelGGL(xc_norm_rowblur<128>, dim3(h, nt), dim3(128), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
+        } else {
+            hipLaunchKernelGGL(xc_norm_rowblur<64>, dim3(h, nt), dim3(64), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
+        }
     }
     hipLaunchKernelGGL(xc_colblur_argmax, dim3((w + 63) / 64, (h + XC_RB5 - 1) / XC_RB5, nt), dim3(256), 0, s,
                        w, h, ws->gauss, fsurf, tmp, dog_dbg, keys);
@@ -1163,7 +1274,8 @@ static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1
 
 static size_t bytes_per_tile(const XcPlan& p)
 {
-    return (size_t)p.w * p.h * ((p.general ? 4 : 2) * sizeof(float2) + 4 * sizeof(float));
+    // power-of-two tiles: one joint spectrum; general sizes: two spectra and their transposes
+    return (size_t)p.w * p.h * ((p.general ? 4 : 1) * sizeof(float2) + 4 * sizeof(float));
 }
 
 static int xcorr_run(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, int n, int tile_w, int tile_h,
@@ -1449,7 +1561,7 @@ int mis_xcorr_surface_u8(mis_ctx* ctx, uint8_t* out)
     if (!rc) rc = xcorr_run(ctx, d1, d2, 1, w, h, nullptr, nullptr, false);   // stages 1-3 only
     if (!rc) {
         XcorrWs* ws = ctx->xc;
-        const float* surf = (const float*)((char*)ws->buf + 2 * N * sizeof(float2));
+        const float* surf = ctx->xc->last_abs;
         hipStream_t s = ctx->stream;
         hipLaunchKernelGGL(xc_quantise_shift, dim3((w + 255) / 256, h), dim3(256), 0, s, w, h,
                            (const unsigned*)ws->meta, surf, d8);
