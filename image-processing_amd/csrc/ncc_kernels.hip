@@ -732,13 +732,15 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     const bool inside = (x < a.W - R) && (y < a.row1);
     const int P = a.pitch;
     const size_t o = (size_t)y * a.out_pitch + x;
-    // merge the chunk keys: lowest chunk wins among equal (truncated) scores
-    int ds = MIS_INVALID_DISP;
+    // merge the chunk keys: the best truncated score wins; a second chunk whose truncated score is
+    // EQUAL is remembered (keys carry 26 bits: two candidates closer than 8e-6 relative look alike),
+    // and the two are told apart further down by their exact scores
+    int ds = MIS_INVALID_DISP, alt = MIS_INVALID_DISP;
     float sec = -1.0e30f;                          // WANT2: best second-peak candidate so far (argmax-kernel scale)
     int xd = 0;                                    // WANT2: +2 / -2 when the disparity two away needs its exact score
+    const size_t plane = (size_t)a.H * a.out_pitch;
     if (inside) {
         float best = -1.0e30f;                     // below any score, above the bias of masked lanes
-        const size_t plane = (size_t)a.H * a.out_pitch;
         constexpr int NKB = NCC_REFINE_KEY_BATCH;  // planes per round trip (independent loads)
         for (int c0 = 0; c0 < nchunk; c0 += NKB) {
             float k4[NKB];
@@ -748,23 +750,17 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
             for (int i = 0; i < NKB; i++) {
                 const uint32_t kb = __builtin_bit_cast(uint32_t, k4[i]);
                 const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
-                if (c0 + i < nchunk && v > best) { best = v; ds = a.dmin + (c0 + i) * 64 + 63 - (int)(kb & 63u); }
+                const int dc = a.dmin + (c0 + i) * 64 + 63 - (int)(kb & 63u);
+                if (c0 + i < nchunk) {
+                    if (v > best) { best = v; ds = dc; alt = MIS_INVALID_DISP; }
+                    else if (v == best && alt == MIS_INVALID_DISP) alt = dc;
+                }
             }
         }
-        if (oIdisp) oIdisp[o] = (int16_t)ds;
-        if (ds == MIS_INVALID_DISP) { oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f; if (WANT2) oPeak2[o] = -1.f; }
-        if (WANT2 && ds != MIS_INVALID_DISP) {
-            const int bc = (ds - a.dmin) >> 6, lw = (ds - a.dmin) & 63;
-            for (int c = 0; c < nchunk; c++) {
-                const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * plane + o]);
-                const int l1 = 63 - (int)(kb & 63u);
-                bool second_plane = (c == bc);
-                if (c == bc + 1 && lw == 63 && l1 == 0) { second_plane = true; xd = 2; }
-                if (c == bc - 1 && lw == 0 && l1 == 63) { second_plane = true; xd = -2; }
-                const uint32_t vb = second_plane ? __builtin_bit_cast(uint32_t, gKeys2[(size_t)c * plane + o]) : kb;
-                const float v = __builtin_bit_cast(float, vb & 0xFFFFFFC0u);
-                if (v > sec) sec = v;
-            }
+        if (oIdisp) oIdisp[o] = (int16_t)ds;       // rewritten below where the exact scores pick the other candidate
+        if (ds == MIS_INVALID_DISP) {
+            oDisp[o] = (float)MIS_INVALID_DISP; oPeak[o] = 0.f;
+            if (WANT2) oPeak2[o] = -1.f;
         }
     }
     const bool valid = inside && ds != MIS_INVALID_DISP;
@@ -799,68 +795,126 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     __syncthreads();
     if (!valid) return;
 
-    const int u = x - ds;                         // window centre in the right image for the winner
-    int Sm = 0, S0 = 0, Sp = 0;                   // disparities ds-1, ds, ds+1 <-> columns u+1, u, u-1
     const uint32_t* pl = tL + lx;                            // column x-R
-    const uint32_t* pr = tR + (u - R - 1 - cbase);           // column u-R-1
+    // exact window correlation with the right window centred at column uc (one candidate)
+    auto exact_sum = [&](int uc) -> int {
+        int S = 0;
+        const uint32_t* pc = tR + (uc - R - cbase);
 #pragma unroll
-    for (int qi = 0; qi < NQ; qi++) {
-        uint32_t m = 0;
+        for (int qi = 0; qi < NQ; qi++) {
+            uint32_t m = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int row = 4 * (qb + qi) + k;
-            if (row >= y - R && row <= y + R) m |= 0xFFu << (8 * k);
-        }
-        if (m == 0) continue;                     // wave-uniform: a wavefront is one row
-        const uint32_t* plq = pl + qi * LC;
-        const uint32_t* prq = pr + qi * NC;
-        // the row's LDS address goes through a register of its own: folded into one base for all quad
-        // rows, the column offsets outgrow the 8-bit fields of ds_read2 and every read costs an add
-        typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
-        uint32_t a32 = (uint32_t)(uintptr_t)(lds_u32_ptr)prq;
-        asm volatile("" : "+v"(a32));
-        const lds_u32_ptr prq3 = (lds_u32_ptr)(uintptr_t)a32;
-        uint32_t rc = prq3[0], rb = prq3[1];
-        if (m == 0xFFFFFFFFu) {                   // all four rows of the quad lie in the window: no masking
-#pragma unroll
-            for (int i = 0; i <= 2 * R; i++) {
-                const uint32_t ra = prq3[i + 2];
-                const uint32_t l = plq[i];
-                Sm = __builtin_amdgcn_sdot4((int)l, (int)ra, Sm, false);
-                S0 = __builtin_amdgcn_sdot4((int)l, (int)rb, S0, false);
-                Sp = __builtin_amdgcn_sdot4((int)l, (int)rc, Sp, false);
-                rc = rb; rb = ra;
+            for (int k = 0; k < 4; k++) {
+                const int row = 4 * (qb + qi) + k;
+                if (row >= y - R && row <= y + R) m |= 0xFFu << (8 * k);
             }
-        } else {
+            if (m == 0) continue;                 // wave-uniform: a wavefront is one row
+            const uint32_t* plq = pl + qi * LC;
+            const uint32_t* pcq = pc + qi * NC;
 #pragma unroll
-            for (int i = 0; i <= 2 * R; i++) {
-                const uint32_t ra = prq3[i + 2];
-                const uint32_t l = plq[i] & m;
-                Sm = __builtin_amdgcn_sdot4((int)l, (int)ra, Sm, false);
-                S0 = __builtin_amdgcn_sdot4((int)l, (int)rb, S0, false);
-                Sp = __builtin_amdgcn_sdot4((int)l, (int)rc, Sp, false);
-                rc = rb; rb = ra;
-            }
+            for (int i = 0; i <= 2 * R; i++) S = __builtin_amdgcn_sdot4((int)(plq[i] & m), (int)pcq[i], S, false);
         }
-    }
-
-    const float nc = gNegc[(size_t)y * P + (x - R)], ng = gNegg[(size_t)y * P + (x - R)], il = gIL[(size_t)y * P + (x - R)];
-    // the right-image tables of the three candidates: six loads issued together (clamped columns), the
-    // range tests applied afterwards; loads inside the tests would be three more exposed round trips
-    float srv3[3], irv3[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int col = min(max(u + 1 - k, 0), a.W - 1);
-        srv3[k] = gRsr[(size_t)y * P + col];
-        irv3[k] = gRir[(size_t)y * P + col];
-    }
-    auto score = [&](int S, int k, int col, int d) -> float {
-        if (d < a.dmin || d > a.dmax || col < 0 || col >= a.W) return __builtin_nanf("");
-        const float tt = __builtin_fmaf(nc, srv3[k], (float)S);
-        const float cov = __builtin_fmaf(ng, srv3[k], tt);
-        return __builtin_fmaf(cov, irv3[k], 0.f);                        // NaN where the window does not fit
+        return S;
     };
-    const float sm = score(Sm, 0, u + 1, ds - 1), s0 = score(S0, 1, u, ds), sp = score(Sp, 2, u - 1, ds + 1);
+    // (loads its own table values: the rare passes that use it must not keep registers alive across the main loop)
+    auto exact_score = [&](int S, int uc) -> float {
+        const float ncx = gNegc[(size_t)y * P + (x - R)], ngx = gNegg[(size_t)y * P + (x - R)];
+        const float srx = gRsr[(size_t)y * P + uc], irx = gRir[(size_t)y * P + uc];
+        const float tt = __builtin_fmaf(ncx, srx, (float)S);
+        const float cov = __builtin_fmaf(ngx, srx, tt);
+        return __builtin_fmaf(cov, irx, 0.f);                                // NaN where the window does not fit
+    };
+    // Exact scores of disparities dcur-1, dcur, dcur+1.
+    float il = 0.f;
+    auto triple = [&](int dcur, float& sm, float& s0, float& sp) {
+        const int u = x - dcur;                       // window centre in the right image for the candidate
+        int Sm = 0, S0 = 0, Sp = 0;                   // disparities dcur-1, dcur, dcur+1 <-> columns u+1, u, u-1
+        const uint32_t* pr = tR + (u - R - 1 - cbase);           // column u-R-1
+#pragma unroll
+        for (int qi = 0; qi < NQ; qi++) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int row = 4 * (qb + qi) + k;
+                if (row >= y - R && row <= y + R) m |= 0xFFu << (8 * k);
+            }
+            if (m == 0) continue;                     // wave-uniform: a wavefront is one row
+            const uint32_t* plq = pl + qi * LC;
+            const uint32_t* prq = pr + qi * NC;
+            // the row's LDS address goes through a register of its own: folded into one base for all quad
+            // rows, the column offsets outgrow the 8-bit fields of ds_read2 and every read costs an add
+            typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+            uint32_t a32 = (uint32_t)(uintptr_t)(lds_u32_ptr)prq;
+            asm volatile("" : "+v"(a32));
+            const lds_u32_ptr prq3 = (lds_u32_ptr)(uintptr_t)a32;
+            uint32_t rc = prq3[0], rb = prq3[1];
+            if (m == 0xFFFFFFFFu) {                   // all four rows of the quad lie in the window: no masking
+#pragma unroll
+                for (int i = 0; i <= 2 * R; i++) {
+                    const uint32_t ra = prq3[i + 2];
+                    const uint32_t l = plq[i];
+                    Sm = __builtin_amdgcn_sdot4((int)l, (int)ra, Sm, false);
+                    S0 = __builtin_amdgcn_sdot4((int)l, (int)rb, S0, false);
+                    Sp = __builtin_amdgcn_sdot4((int)l, (int)rc, Sp, false);
+                    rc = rb; rb = ra;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i <= 2 * R; i++) {
+                    const uint32_t ra = prq3[i + 2];
+                    const uint32_t l = plq[i] & m;
+                    Sm = __builtin_amdgcn_sdot4((int)l, (int)ra, Sm, false);
+                    S0 = __builtin_amdgcn_sdot4((int)l, (int)rb, S0, false);
+                    Sp = __builtin_amdgcn_sdot4((int)l, (int)rc, Sp, false);
+                    rc = rb; rb = ra;
+                }
+            }
+        }
+        const float nc = gNegc[(size_t)y * P + (x - R)], ng = gNegg[(size_t)y * P + (x - R)];
+        il = gIL[(size_t)y * P + (x - R)];
+        // the right-image tables of the three disparities: six loads issued together (clamped columns), the
+        // range tests applied afterwards; loads inside the tests would be three more exposed round trips
+        float srv3[3], irv3[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int col = min(max(u + 1 - k, 0), a.W - 1);
+            srv3[k] = gRsr[(size_t)y * P + col];
+            irv3[k] = gRir[(size_t)y * P + col];
+        }
+        auto score = [&](int S, int k, int col, int d) -> float {
+            if (d < a.dmin || d > a.dmax || col < 0 || col >= a.W) return __builtin_nanf("");
+            const float tt = __builtin_fmaf(nc, srv3[k], (float)S);
+            const float cov = __builtin_fmaf(ng, srv3[k], tt);
+            return __builtin_fmaf(cov, irv3[k], 0.f);                        // NaN where the window does not fit
+        };
+        sm = score(Sm, 0, u + 1, dcur - 1); s0 = score(S0, 1, u, dcur); sp = score(Sp, 2, u - 1, dcur + 1);
+    };
+    float sm, s0, sp;
+    triple(ds, sm, s0, sp);
+    // Two chunks delivered EQUAL truncated scores: the exact centre scores decide, the lower disparity keeps
+    // a true tie.  Rare (repeated image content); only wavefronts that hold such a pixel take the second pass.
+    const bool has = alt != MIS_INVALID_DISP;
+    if (__any(has)) {
+        float tm, t0, tp;
+        triple(has ? alt : ds, tm, t0, tp);
+        if (has && t0 > s0) {
+            sm = tm; s0 = t0; sp = tp; ds = alt;
+            if (oIdisp) oIdisp[o] = (int16_t)ds;
+        }
+    }
+    if (WANT2) {
+        const int bc = (ds - a.dmin) >> 6, lw = (ds - a.dmin) & 63;
+        for (int c = 0; c < nchunk; c++) {
+            const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * plane + o]);
+            const int l1 = 63 - (int)(kb & 63u);
+            bool second_plane = (c == bc);
+            if (c == bc + 1 && lw == 63 && l1 == 0) { second_plane = true; xd = 2; }
+            if (c == bc - 1 && lw == 0 && l1 == 63) { second_plane = true; xd = -2; }
+            const uint32_t vb = second_plane ? __builtin_bit_cast(uint32_t, gKeys2[(size_t)c * plane + o]) : kb;
+            const float v = __builtin_bit_cast(float, vb & 0xFFFFFFC0u);
+            if (v > sec) sec = v;
+        }
+    }
     float delta = 0.f;
     if (sm == sm && sp == sp) {
         const float den = 2.f * (sm - 2.f * s0 + sp);
@@ -874,28 +928,10 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
         const int d2 = ds + xd;
         const bool need = xd != 0 && d2 >= a.dmin && d2 <= a.dmax;
         if (__any(need)) {
-            const int u2 = need ? x - d2 : u;
-            int Sx = 0;
-            const uint32_t* px = tR + (u2 - R - cbase);
-#pragma unroll
-            for (int qi = 0; qi < NQ; qi++) {
-                uint32_t m = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int row = 4 * (qb + qi) + k;
-                    if (row >= y - R && row <= y + R) m |= 0xFFu << (8 * k);
-                }
-                if (m == 0) continue;
-                const uint32_t* plq = pl + qi * LC;
-                const uint32_t* pxq = px + qi * NC;
-#pragma unroll
-                for (int i = 0; i <= 2 * R; i++) Sx = __builtin_amdgcn_sdot4((int)(plq[i] & m), (int)pxq[i], Sx, false);
-            }
+            const int u2 = need ? x - d2 : x - ds;
+            const int Sx = exact_sum(u2);
             if (need && u2 >= 0 && u2 < a.W) {
-                const float srx = gRsr[(size_t)y * P + u2], irx = gRir[(size_t)y * P + u2];
-                const float tt = __builtin_fmaf(nc, srx, (float)Sx);
-                const float cov = __builtin_fmaf(ng, srx, tt);
-                const float sx = __builtin_fmaf(cov, irx, 0.f);              // NaN where the window does not fit
+                const float sx = exact_score(Sx, u2);
                 if (sx > sec) sec = sx;
             }
         }

@@ -53,6 +53,7 @@ def test_deterministic_and_strip_invariant(ctx, full):
     assert np.array_equal(p.cpu().numpy().view(np.uint32), out["peak"].view(np.uint32))
     d2 = torch.full_like(d, -1.0)
     p2 = torch.full_like(d, -1.0)
+    torch.cuda.synchronize()           # the fills run on torch's stream, the library on its own: order them
     ctx.ncc_dense_torch(WIN, -D, D, d2, p2, row0=0, nrows=5000)
     ctx.ncc_dense_torch(WIN, -D, D, d2, p2, row0=5000, nrows=SIZE - 5000)
     ctx.synchronize()

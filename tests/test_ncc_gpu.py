@@ -113,6 +113,7 @@ def test_row_strips_equal_the_full_frame(ctx, dmin, dmax, dtype):
     ctx.ncc_dense_torch(11, dmin, dmax, full_d, full_p)
     part_d = torch.full_like(full_d, 12345.0)
     part_p = torch.full_like(full_d, 12345.0)
+    torch.cuda.synchronize()           # the fills run on torch's stream, the library on its own: order them
     for row0, n in partition.row_strips(90, 3):
         ctx.ncc_dense_torch(11, dmin, dmax, part_d, part_p, row0=row0, nrows=n)
     ctx.synchronize()
@@ -322,6 +323,7 @@ def test_strips_in_any_order_build_only_their_rows(ctx, dtype):
     ctx.synchronize()
     ctx.bind_pair_torch(tl, tr)                          # drops the tables
     d = torch.full_like(full_d, 777.0); p = torch.full_like(full_d, 777.0)
+    torch.cuda.synchronize()           # the fills run on torch's stream, the library on its own: order them
     order = [(600, 100), (0, 130), (300, 150), (130, 170), (440, 170), (250, 120), (0, 700)]
     for row0, n in order[:-1]:
         ctx.ncc_dense_torch(9, -20, 45, d, p, row0=row0, nrows=n)
@@ -330,4 +332,7 @@ def test_strips_in_any_order_build_only_their_rows(ctx, dtype):
     for row0, n in order[:-1]:
         covered[row0:row0 + n] = True
     assert covered.all()
-    assert torch.equal(d, full_d) and torch.equal(p, full_p)
+    bad = (d != full_d) | (p != full_p)
+    ys, xs = torch.nonzero(bad, as_tuple=True)
+    assert not bad.any(), "%d pixels differ: rows %s, columns %d..%d" % (
+        int(bad.sum()), sorted(set(ys.cpu().tolist()))[:12], int(xs.min()), int(xs.max()))
