@@ -20,9 +20,11 @@
 // Exactness: pixels are shifted by 128 into [-128,127] (NCC does not change); every product,
 // column sum and window sum is an integer below 2^24 and therefore exact in f32.
 #include "ncc_shared.h"
+#include "ncc_mfma.h"
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 struct NccWs {
     // per-pixel tables, pitch P elements per row, H rows
@@ -715,8 +717,11 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     const float* __restrict__ gNegc, const float* __restrict__ gNegg, const float* __restrict__ gIL,
     const float* __restrict__ gRsr, const float* __restrict__ gRir, const float* __restrict__ gKeys, int nchunk,
     float* __restrict__ oDisp, float* __restrict__ oPeak, int16_t* __restrict__ oIdisp,
-    const float* __restrict__ gKeys2, float* __restrict__ oPeak2)
+    const float* __restrict__ gKeys2, float* __restrict__ oPeak2, int range_tiles)
 {
+    // range_tiles == 0: planes of the vector argmax kernel (chunk of 64 disparities per plane, 26-bit score,
+    // 63 - lane below); > 0: planes of the matrix-core kernel (range of 32*range_tiles right columns per
+    // plane, 25-bit score, column index in the range below)
     using Cfg = NccRefineCfg<R>;
     constexpr int NQ = Cfg::NQ, LC = Cfg::LC;
     extern __shared__ __attribute__((aligned(16))) uint32_t ncc_refine_lds[];
@@ -745,12 +750,17 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
         for (int c0 = 0; c0 < nchunk; c0 += NKB) {
             float k4[NKB];
 #pragma unroll
-            for (int i = 0; i < NKB; i++) k4[i] = gKeys[(size_t)min(c0 + i, nchunk - 1) * plane + o];
+            for (int i = 0; i < NKB; i++) {
+                // planes in ascending order of disparity (the matrix-core kernel's planes ascend in right column)
+                const int pc = min(c0 + i, nchunk - 1);
+                k4[i] = gKeys[(size_t)(range_tiles ? nchunk - 1 - pc : pc) * plane + o];
+            }
 #pragma unroll
             for (int i = 0; i < NKB; i++) {
                 const uint32_t kb = __builtin_bit_cast(uint32_t, k4[i]);
-                const float v = __builtin_bit_cast(float, kb & 0xFFFFFFC0u);
-                const int dc = a.dmin + (c0 + i) * 64 + 63 - (int)(kb & 63u);
+                const float v = __builtin_bit_cast(float, kb & (range_tiles ? 0xFFFFFF80u : 0xFFFFFFC0u));
+                const int dc = range_tiles ? a.dmax + ((x - R) & 63) - 32 * range_tiles * (nchunk - 1 - (c0 + i)) - (int)(kb & 127u)
+                                           : a.dmin + (c0 + i) * 64 + 63 - (int)(kb & 63u);
                 if (c0 + i < nchunk) {
                     if (v > best) { best = v; ds = dc; alt = MIS_INVALID_DISP; }
                     else if (v == best && alt == MIS_INVALID_DISP) alt = dc;
@@ -897,7 +907,7 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     if (__any(has)) {
         float tm, t0, tp;
         triple(has ? alt : ds, tm, t0, tp);
-        if (has && t0 > s0) {
+        if (has && (t0 > s0 || (t0 == s0 && alt < ds))) {
             sm = tm; s0 = t0; sp = tp; ds = alt;
             if (oIdisp) oIdisp[o] = (int16_t)ds;
         }
@@ -1084,7 +1094,39 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
         hipLaunchKernelGGL((ncc_refine_kernel<R, WANT2>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
                            lds, ctx->stream,
                            a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nplanes, d_disp, d_peak, d_idisp,
-                           keys2, d_peak2);
+                           keys2, d_peak2, 0);
+    }
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+
+// Matrix-core path: one key plane per range of 32*NCC_MF_T right columns, no tail kernel (the tiles on the
+// edge of the disparity range are masked per element).
+template <int R>
+static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
+{
+    NccWs* w = ctx->ncc;
+    const int nd = a.dmax - a.dmin + 1;
+    const int nranges = NccMfCfg<R>::ranges(nd);
+    const int nblocks = (a.W - 2 * R + 63) / 64;
+    const size_t plane_px = (size_t)a.H * a.W;
+    int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, (size_t)nranges * plane_px * sizeof(float));
+    if (rc) return rc;
+    a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
+    mis_prof_mark(ctx);                            // tables done
+    hipLaunchKernelGGL(ncc_mfma_argmax_kernel<R>, dim3((unsigned)(nblocks * a.nbands * nranges)), dim3(64), 0, ctx->stream,
+                       a, nblocks, nranges, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+    mis_prof_mark(ctx);
+    rc = ncc_join(ctx, w);                         // vertical packs, border
+    if (rc) return rc;
+    {
+        const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
+        if (lds > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ncc_refine_kernel<R, false>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
+                           lds, ctx->stream,
+                           a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nranges, d_disp, d_peak, d_idisp,
+                           (const float*)nullptr, (float*)nullptr, NCC_MF_T);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
@@ -1173,10 +1215,13 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
         if (strips * bands256 * (nd / 64 > 0 ? nd / 64 : 1) >= 6 * 5120) a.band_rows = 256;
     }
     a.nchunk = total_chunks;
+    static const int mfma_env = [] { const char* e = getenv("MISTEREO_NCC_MFMA"); return e ? atoi(e) : 1; }();
+    const bool use_mfma = (mfma_env != 0 && !d_peak2);
     // wavefronts per SIMD the register budget is set for: 5 up to 23 x 23 windows, 4 beyond; the
     // second-peak variant keeps 16 more keys in registers: 4 wavefronts for every window
 #define NCC_MW(RR) ((RR) <= 11 ? 5 : 4)
 #define NCC_CASE(RR) case RR: rc = d_peak2 ? ncc_launch_fast<RR, 32, 4, true>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
+                               : use_mfma ? ncc_launch_mfma<RR>(ctx, a, d_disp, d_peak, d_idisp) \
                                : ncc_launch_fast<RR, 32, NCC_MW(RR), false>(ctx, a, d_disp, d_peak, d_idisp, nullptr); break;
     switch (r) {
         NCC_CASE(1) NCC_CASE(2) NCC_CASE(3) NCC_CASE(4) NCC_CASE(5) NCC_CASE(6) NCC_CASE(7) NCC_CASE(8)
