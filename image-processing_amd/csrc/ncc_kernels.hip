@@ -1114,11 +1114,33 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     if (rc) return rc;
     a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
     mis_prof_mark(ctx);                            // tables done
-    hipLaunchKernelGGL(ncc_mfma_argmax_kernel<R>, dim3((unsigned)(nblocks * a.nbands * nranges)), dim3(64), 0, ctx->stream,
-                       a, nblocks, nranges, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+    {
+        // ranges whose tiles all lie inside the disparity range: diagonals T*p - (NB-1) .. T*p + T - 1 within [1, gF]
+        const int gF = nd >= 32 ? (nd - 32) / 32 : -1;
+        int p_lo = (NCC_MF_NB + NCC_MF_T - 1) / NCC_MF_T;
+        int p_hi = gF - NCC_MF_T + 1 >= 0 ? (gF - NCC_MF_T + 1) / NCC_MF_T : -1;
+        if (p_hi >= nranges) p_hi = nranges - 1;
+        if (p_hi < p_lo) { p_lo = nranges; p_hi = nranges - 1; }      // none
+        const int n_in = p_hi - p_lo + 1, n_edge = nranges - n_in;
+        // the edge ranges first: their wavefronts take longer, the interior ones fill the machine behind them
+        if (n_edge > 0)
+            hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, true>), dim3((unsigned)(nblocks * a.nbands * n_edge)), dim3(64), 0, ctx->stream,
+                               a, nblocks, n_edge, n_in > 0 ? p_lo : nranges, p_hi + 1, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+        if (n_in > 0)
+            hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, false>), dim3((unsigned)(nblocks * a.nbands * n_in)), dim3(64), 0, ctx->stream,
+                               a, nblocks, n_in, p_lo, 0, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+    }
     mis_prof_mark(ctx);
     rc = ncc_join(ctx, w);                         // vertical packs, border
     if (rc) return rc;
+#ifdef NCC_MF_DEBUG
+    {
+        const int pa = getenv("MISTEREO_DBG_A") ? atoi(getenv("MISTEREO_DBG_A")) : 0, pb = getenv("MISTEREO_DBG_B") ? atoi(getenv("MISTEREO_DBG_B")) : 1;
+        MIS_HIP(ctx, hipMemcpyAsync(d_disp, w->keys + (size_t)pa * plane_px, plane_px * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        MIS_HIP(ctx, hipMemcpyAsync(d_peak, w->keys + (size_t)pb * plane_px, plane_px * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return MIS_OK;
+    }
+#endif
     {
         const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
         if (lds > 64 * 1024)
@@ -1216,12 +1238,12 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     }
     a.nchunk = total_chunks;
     static const int mfma_env = [] { const char* e = getenv("MISTEREO_NCC_MFMA"); return e ? atoi(e) : 1; }();
-    const bool use_mfma = (mfma_env != 0 && !d_peak2);
+    const bool use_mfma = (mfma_env != 0 && !d_peak2 && r <= NCC_MF_MAX_R);
     // wavefronts per SIMD the register budget is set for: 5 up to 23 x 23 windows, 4 beyond; the
     // second-peak variant keeps 16 more keys in registers: 4 wavefronts for every window
 #define NCC_MW(RR) ((RR) <= 11 ? 5 : 4)
 #define NCC_CASE(RR) case RR: rc = d_peak2 ? ncc_launch_fast<RR, 32, 4, true>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
-                               : use_mfma ? ncc_launch_mfma<RR>(ctx, a, d_disp, d_peak, d_idisp) \
+                               : use_mfma ? ncc_launch_mfma<(RR <= NCC_MF_MAX_R ? RR : NCC_MF_MAX_R)>(ctx, a, d_disp, d_peak, d_idisp) \
                                : ncc_launch_fast<RR, 32, NCC_MW(RR), false>(ctx, a, d_disp, d_peak, d_idisp, nullptr); break;
     switch (r) {
         NCC_CASE(1) NCC_CASE(2) NCC_CASE(3) NCC_CASE(4) NCC_CASE(5) NCC_CASE(6) NCC_CASE(7) NCC_CASE(8)

@@ -1,4 +1,4 @@
-// Dense NCC argmax on the matrix cores (8-bit pairs), gfx950.
+// Dense NCC argmax on the matrix cores (8-bit pairs, windows up to 21 x 21), gfx950.
 //
 // The window correlation of a left pixel x with the right pixels x' = x - d,
 //     S(x, x') = sum over window rows j and taps i of L'(x+i, y+j) * R'(x'+i, y+j),
@@ -6,14 +6,24 @@
 // Walking down the rows, S(y) = S(y-1) + (row y+r) - (row y-r-1), and both rows ride one product with the
 // accumulator as C operand: k runs over (tap, {entering row, leaving row}) pairs, which is exactly the
 // layout of the packed row pairs the tables hold (half2(p(y), -+p(y-W)) per pixel; the left image carries
-// the minus sign).  So one v_mfma_f32_32x32x16_f16 per 8 taps slides 1024 window sums one row down; all
-// values are integers below 2^24, exact in f32.
+// the minus sign).  So one v_mfma_f32_32x32x16_f16 per 8 taps slides 1024 window sums one row down.
+//
+// The integer part of the mean correction rides the same products.  The score needs
+//     cov = S - S_L S_R / N = (S + c S_R) + g S_R,   c = -round(S_L / N) (integer), g = -(S_L - N round(S_L/N)) / N,
+// and T = S + c S_R slides too: T(y) - T(y-1) = [S(y) - S(y-1)] + c(y) S_R(y) - c(y-1) S_R(y-1).  With
+// S_R = 256 s1 + s0 (s1 = floor(S_R / 256), 0 <= s0 < 256) the two terms are four more k: A carries
+// (s1, s0) of this and of the previous row, B carries (256 c, c) and -(256 c, c); they sit in the two taps the
+// products have to spare behind the window's last tap.  Every value is an integer, exact in f16 as an operand,
+// and every partial sum stays below 2^24 (|S| and |c S_R| <= 128^2 * 441), so the accumulators hold T exactly
+// in whatever order the matrix unit adds.  Windows wider than 21 do not keep that bound and stay on the
+// vector kernel.
 //
 //   wavefront   <-> 64 left columns (two 32-column blocks) x one range of 32*T right columns x a band of rows
-//   accumulators<-> T x 2 tiles of 32 x 32 window sums; column x on the lane, right column x' in the registers
-//   cov         =   S - S_L S_R / N as a second product on the accumulators (v_mfma_f32_32x32x2_f32, an exact
-//                   fmaf chain: k = 0 carries -round(S_L/N), k = 1 the remainder, as in the vector kernel)
-//   score       =   cov / sigma_R (one multiply; 1/sigma_L is common to a column and does not move the argmax)
+//   accumulators<-> T x 2 tiles of 32 x 32 values of T(x, x'); column x on the lane, right column x' in the registers
+//   score       =   (T + g S_R) / sigma_R, evaluated as fma(T, 1/sigma_R, g * (S_R / sigma_R)): the second
+//                   operand pair comes per right column from LDS (two broadcast reads per 4 registers).
+//                   1/sigma_L is common to a column and does not move the argmax; the refinement kernel
+//                   recomputes the winners' scores exactly.
 //   argmax      :   a lane owns its column, so the maximum over x' is a running v_max3 over registers; keys
 //                   carry 26 bits of the score and the register id below, the two half-waves (which hold
 //                   interleaved groups of 4 rows) meet once per row through one v_permlane32_swap
@@ -26,6 +36,8 @@
 
 #include "ncc_shared.h"
 
+#include <type_traits>
+
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -34,10 +46,11 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #define NCC_MF_T 3           // 32-column tiles of right columns per wavefront
 #define NCC_MF_NB 2          // 32-column blocks of left columns per wavefront
 #define NCC_MF_LOW (-3.0e38f)
+#define NCC_MF_MAX_R 10      // widest window whose partial sums stay below 2^24
 
 template <int R>
 struct NccMfCfg {
-    static constexpr int KS = (2 * R + 1 + 7) / 8;              // products of 8 taps (16 k) per row step
+    static constexpr int KS = (2 * R + 1 + 2 + 7) / 8;          // products of 8 taps (16 k) per row step: the window's taps and two spare ones
     static constexpr int SEGR = 32 * NCC_MF_T + 8 * KS;         // staged right pixels
     static constexpr int SEGL = 32 * NCC_MF_NB + 8 * KS;        // staged left pixels
     static constexpr int QR = SEGR / 4, QL = SEGL / 4;          // 16-byte positions per copy
@@ -46,17 +59,13 @@ struct NccMfCfg {
     static int ranges(int nd) { return (((nd + 30) >> 5) + NCC_MF_NB + NCC_MF_T - 1) / NCC_MF_T; }
 };
 
-// v_max_f32 semantics (a quiet NaN loses) without the canonicalisation the compiler puts in front of fmaxf
-__device__ __forceinline__ float ncc_max3(float a, float b, float c)
-{
-    float o;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
-    return o;
-}
-
-template <int R>
+// EDGE = false: the ranges [seg0, seg0 + nranges), whose tiles all lie inside the disparity range: no tests.
+// EDGE = true: the other ranges, [0, seg0) and [seg1, seg1 + nranges - seg0): tiles outside the disparity range are
+// skipped, tiles on its edge masked per element.  Two kernels rather than two loops in one kernel: a kernel's
+// register allocation covers all its loops, and with both loops present the 96 accumulators spill.
+template <int R, bool EDGE>
 __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
-    NccArgs a, int nblocks, int nranges,
+    NccArgs a, int nblocks, int nranges, int seg0, int seg1,
     const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
     const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr, const float* __restrict__ gRir,
     float* __restrict__ oKeys)
@@ -64,12 +73,15 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     using Cfg = NccMfCfg<R>;
     constexpr int KS = Cfg::KS, T = NCC_MF_T, NB = NCC_MF_NB, CS = Cfg::CS, QR = Cfg::QR, QL = Cfg::QL;
     constexpr int WN = 2 * R + 1;
+    static_assert(R <= NCC_MF_MAX_R, "partial sums must stay below 2^24");
     static_assert(NB == 2, "the half-wave merge pairs two column blocks");
     static_assert(16 * T <= 64, "register tags are inline constants");
+    static_assert(8 * KS - 2 > 2 * R, "two spare taps behind the window");
     __shared__ __attribute__((aligned(16))) float sR[4 * CS];
     __shared__ __attribute__((aligned(16))) float sL[4 * CS];
-    __shared__ __attribute__((aligned(16))) float sSr[32 * T];
-    __shared__ __attribute__((aligned(16))) float sIr[32 * T];
+    __shared__ __attribute__((aligned(16))) float sIr[32 * T];          // 1 / sigma_R of the row being scored
+    __shared__ __attribute__((aligned(16))) float sQ[32 * T];           // S_R / sigma_R
+    __shared__ __attribute__((aligned(16))) uint32_t sC[2][32 * T];     // half2(s1, s0) of S_R, rows of even / odd parity
 
     const int lane = threadIdx.x, n = lane & 31, h = lane >> 5;
     // Workgroups are dealt to the 8 XCDs round-robin; remap so that every XCD works through a contiguous
@@ -82,6 +94,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         const int q = total >> 3, rem = total & 7;
         const int wid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
         range = wid % nranges;
+        range = EDGE ? (range < seg0 ? range : seg1 + (range - seg0)) : seg0 + range;
         block = (wid / nranges) % nblocks;
         band = wid / (nranges * nblocks);
     }
@@ -95,10 +108,21 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     const int XR0 = X0 - a.dmax + 32 * T * range;   // raster column of the range's first right pixel
     const int P = a.pitch;
 
-    // tile (t, c): right columns XR0 + 32t + m, left columns X0 + 32c + n; d = dmax - 32g + (n - m), g = T*range + t - c
-    auto tile_g = [&](int t, int c) { return T * range + t - c; };
-    auto tile_any = [&](int t, int c) { const int g = tile_g(t, c); return g >= 0 && g <= G; };
-    auto tile_full = [&](int t, int c) { const int g = tile_g(t, c); return g >= 1 && 32 * g + 31 <= nd - 1; };
+    // tile (t, c): right columns XR0 + 32t + m, left columns X0 + 32c + n; d = dmax - 32g + (n - m), g = T*range + t - c.
+    // A tile is skipped when no element lies in the disparity range (g < 0 or g > G), masked per element when
+    // some do not (only in the first and last ranges).
+    uint32_t any_bits = 0, part_bits = 0;           // bit t*NB + c
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const int g = T * range + t - c;
+            const bool any = g >= 0 && g <= G, full = g >= 1 && 32 * g + 31 <= nd - 1;
+            any_bits |= (uint32_t)any << (t * NB + c);
+            part_bits |= (uint32_t)(any && !full) << (t * NB + c);
+        }
+    any_bits = __builtin_amdgcn_readfirstlane(any_bits);
+    part_bits = __builtin_amdgcn_readfirstlane(part_bits);
 
     // ---- staging: global -> registers (a row ahead) -> LDS ----
     // position s of the 16-byte grid: copy s / Q, slot s % Q; copy c, slot q holds pixels 4q+c .. 4q+c+3
@@ -111,7 +135,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         okL[r2] = s < 4 * QL;
         const int cR = okR[r2] ? s / QR : 0, qR = okR[r2] ? s % QR : 0;
         const int cL = okL[r2] ? s / QL : 0, qL = okL[r2] ? s % QL : 0;
-        colR[r2] = XR0 - R + 4 * qR + cR;      // tap 0 of the window centred at XR0 is column XR0 - R
+        colR[r2] = XR0 - R + 4 * qR + cR;           // tap 0 of the window centred at XR0 is column XR0 - R
         dstR[r2] = cR * CS + 4 * qR;
         colL[r2] = X0 - R + 4 * qL + cL; dstL[r2] = cL * CS + 4 * qL;
     }
@@ -121,6 +145,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     // row's ends are put right at publish time (only wavefronts at the raster's left and right edge)
     auto clamp4 = [&](int col) { return min(max(col, 0), P - 4); };
     const int ccR0 = clamp4(colR[0]), ccR1 = clamp4(colR[1]), ccT = clamp4(colT);
+    const bool fixup = (ccR0 != colR[0]) || (ccR1 != colR[1]) || (ccT != colT);
     // element k of the vector wanted at column col, from the vector loaded at column cc; fill outside [0, lim)
     auto fix4 = [&](u32x4_t v, int col, int cc, int lim, uint32_t fill) -> u32x4_t {
         u32x4_t o;
@@ -132,15 +157,21 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         }
         return o;
     };
-    const int nlcol = 64 * block + 32 * 0 + n;      // left tables are stored shifted by R columns: entry x-R describes column x
+    const int nlcol = 64 * block + n;               // left tables are stored shifted by R columns: entry x-R describes column x
     u32x4_t fr[2], fl[2], fsr, fir;
-    float fnl[NB];
-    auto fetch = [&](int ynew, int yout, bool stats) {
-        const uint32_t* rp = gRpack + (size_t)ynew * P;
-        const uint32_t* lp = gLpack + (size_t)ynew * P;
-        const float* sp = gRsr + (size_t)(stats ? yout : 0) * P;
-        const float* ip = gRir + (size_t)(stats ? yout : 0) * P;
-        const float* np = (h ? gNegg : gNegc) + (size_t)(stats ? yout : 0) * P;
+    float fnc[NB], fng[NB];
+    // every load is issued unconditionally (a load inside a conditional block is waited for at its end);
+    // rows are clamped into the band instead: the statistics fetched for warm-up rows and after the last row
+    // are finite and never scored
+    const int ylast = yb1 - 1 + R;
+    auto fetch = [&](int ynew) {
+        const int yn = min(ynew, ylast), yo = min(max(yn - R, yb0), yb1 - 1);
+        const uint32_t* rp = gRpack + (size_t)yn * P;
+        const uint32_t* lp = gLpack + (size_t)yn * P;
+        const float* sp = gRsr + (size_t)yo * P;
+        const float* ip = gRir + (size_t)yo * P;
+        const float* cp = gNegc + (size_t)yo * P;
+        const float* gp = gNegg + (size_t)yo * P;
         __builtin_memcpy(&fr[0], rp + ccR0, 16);
         __builtin_memcpy(&fr[1], rp + ccR1, 16);
         __builtin_memcpy(&fl[0], lp + colL[0], 16);
@@ -148,23 +179,41 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         __builtin_memcpy(&fsr, sp + ccT, 16);
         __builtin_memcpy(&fir, ip + ccT, 16);
 #pragma unroll
-        for (int c = 0; c < NB; c++) fnl[c] = np[nlcol + 32 * c];
+        for (int c = 0; c < NB; c++) { fnc[c] = cp[nlcol + 32 * c]; fng[c] = gp[nlcol + 32 * c]; }
     };
     const uint32_t qnan = 0x7FC00000u;
-    auto publish = [&](bool stats, bool warm) {
+    // row: the output row the statistics belong to (its parity picks the slot of the (s1, s0) pairs)
+    auto publish = [&](bool warm, int row) {
         if (warm) {                                  // nothing leaves the window yet: drop the leaving-row halves of the left row
 #pragma unroll
             for (int e = 0; e < 4; e++) { fl[0][e] &= 0x0000FFFFu; fl[1][e] &= 0x0000FFFFu; }
         }
-        if (ccR0 != colR[0]) fr[0] = fix4(fr[0], colR[0], ccR0, P, 0u);
-        if (ccR1 != colR[1]) fr[1] = fix4(fr[1], colR[1], ccR1, P, 0u);
+        if (fixup) {
+            fr[0] = fix4(fr[0], colR[0], ccR0, P, 0u);
+            fr[1] = fix4(fr[1], colR[1], ccR1, P, 0u);
+            fsr = fix4(fsr, colT, ccT, P, 0u);
+            fir = fix4(fir, colT, ccT, P, qnan);
+        }
         if (okR[0]) *(u32x4_t*)(sR + dstR[0]) = fr[0];
         if (okR[1]) *(u32x4_t*)(sR + dstR[1]) = fr[1];
         if (okL[0]) *(u32x4_t*)(sL + dstL[0]) = fl[0];
         if (okL[1]) *(u32x4_t*)(sL + dstL[1]) = fl[1];
-        if (stats) {
-            if (ccT != colT) { fsr = fix4(fsr, colT, ccT, P, 0u); fir = fix4(fir, colT, ccT, P, qnan); }
-            if (okT) { *(u32x4_t*)(sSr + 4 * lane) = fsr; *(u32x4_t*)(sIr + 4 * lane) = fir; }
+        if (okT) {
+            const f32x4_t srv = __builtin_bit_cast(f32x4_t, fsr), irv = __builtin_bit_cast(f32x4_t, fir);
+            const f32x4_t q4 = srv * irv;
+            const f32x4_t s1v = __builtin_elementwise_floor(srv * (1.0f / 256.0f));
+            const f32x4_t s0v = srv - 256.0f * s1v;      // exact: integers below 2^17
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                half2_t p;
+                p.x = (_Float16)s1v[e]; p.y = (_Float16)s0v[e];
+                pk[e] = __builtin_bit_cast(uint32_t, p);
+            }
+            const u32x4_t cv = { pk[0], pk[1], pk[2], pk[3] };
+            *(u32x4_t*)(sIr + 4 * lane) = fir;
+            *(f32x4_t*)(sQ + 4 * lane) = q4;
+            *(u32x4_t*)(&sC[row & 1][4 * lane]) = cv;
         }
     };
 
@@ -172,6 +221,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     const int c4 = n & 3;
     const int oLane = c4 * CS + (n - c4) + 4 * h;   // pixel n + 4h of copy c4, 16-byte aligned
     const uint32_t keep_h0 = h ? 0u : 0xFFFFFFFFu;  // taps past the window in the upper half-wave's share of a product
+    const uint32_t kmask = 0xFFFFFFC0u;
 
     f32x16_t acc[T][NB];
 #pragma unroll
@@ -180,21 +230,13 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         for (int c = 0; c < NB; c++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[t][c][i] = 0.f;
+    // (s1, s0) slots start finite: they are multiplied by zero until the first scored row
+    for (int i = lane; i < 2 * 32 * T; i += 64) (&sC[0][0])[i] = 0u;
 
-    fetch(yb0 - R, yb0 - 2 * R, false);
-    publish(false, true);
-    float nl[NB] = { 0.f, 0.f };
-
-    const uint32_t kmask = 0xFFFFFFC0u;
-    for (int st = 0; st < nsteps; st++) {
-        const int ynew = yb0 - R + st;
-        const int yout = ynew - R;
-        const bool score = (st >= 2 * R);
-        const bool have_next = (st + 1 < nsteps);
-        if (have_next) fetch(ynew + 1, yout + 1, st + 1 >= 2 * R);
-
-        // left operands of this row: B[k][x], 8 k per lane and product
-        u32x4_t bop[NB][KS];
+    // left operands of the current row: B[k][x], 8 k per lane and product.  The last product's two spare taps
+    // (upper half-wave, elements 2 and 3) carry the correction pairs cur = (256 c, c) and prv = -(256 c, c) of the
+    // previous row.
+    auto load_b = [&](u32x4_t (&bop)[NB][KS], const uint32_t (&cur)[NB], const uint32_t (&prv)[NB]) {
 #pragma unroll
         for (int c = 0; c < NB; c++)
 #pragma unroll
@@ -203,85 +245,173 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int tap0 = 8 * kk + e, tap1 = tap0 + 4;        // this element's tap in the lower / upper half-wave
-                    if (tap0 > 2 * R) v[e] = 0u;
+                    if (kk == KS - 1 && e >= 2) {
+                        const uint32_t lo = tap0 > 2 * R ? 0u : v[e];
+                        v[e] = h ? (e == 2 ? cur[c] : prv[c]) : lo;
+                    } else if (tap0 > 2 * R) v[e] = 0u;
                     else if (tap1 > 2 * R) v[e] &= keep_h0;
                 }
                 bop[c][kk] = v;
             }
+    };
+    // right operands of tile t: A[x'][k]; the spare taps carry (s1, s0) of the row being scored and of the row before
+    auto load_a = [&](int t, u32x4_t (&aop)[KS], int row) {
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) aop[kk] = *(const u32x4_t*)(sR + oLane + 32 * t + 8 * kk);
+        uint32_t ccur = sC[row & 1][32 * t + n], cprv = sC[(row & 1) ^ 1][32 * t + n];
+        asm volatile("" : "+v"(ccur), "+v"(cprv));   // both reads in every lane: inside a branch on h they would wait for all earlier reads
+        aop[KS - 1][2] = h ? ccur : aop[KS - 1][2];
+        aop[KS - 1][3] = h ? cprv : aop[KS - 1][3];
+    };
+    auto slide = [&](int t, int c, const u32x4_t (&aop)[KS], const u32x4_t (&bop)[NB][KS]) {
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++)
+            acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, aop[kk]),
+                                                              __builtin_bit_cast(half8_t, bop[c][kk]), acc[t][c], 0, 0, 0);
+    };
+    // (256 c, c) as a pair of halves; c is an integer of magnitude <= 128
+    auto cpair = [&](float c) {
+        half2_t p;
+        p.x = (_Float16)(256.0f * c); p.y = (_Float16)c;
+        return __builtin_bit_cast(uint32_t, p);
+    };
 
+    // the half-waves' keys of a row -> one key per left column -> key plane
+    auto emit = [&](float b0, float b1, int yout) {
+        // the two half-waves hold different right columns of the same left column: bring them together
+        // (lanes 0-31 then own block 0, lanes 32-63 block 1), compare on the 26-bit scores, the larger
+        // right column (lower disparity) keeps a tie
+        float k0 = b0, k1 = b1;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(k0), "+v"(k1));   // k0: lower half-wave's keys, k1: upper's
+        auto jof = [&](float k, int hh) {
+            const uint32_t tg = __builtin_bit_cast(uint32_t, k) & 63u;
+            return (int)(32u * (tg >> 4) + 8u * ((tg >> 2) & 3u) + (tg & 3u)) + 4 * hh;
+        };
+        const int j0 = jof(k0, 0), j1 = jof(k1, 1);
+        const float s0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, k0) & kmask);
+        const float s1 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, k1) & kmask);
+        const bool up = (s1 > s0) || (s1 == s0 && j1 > j0);
+        const uint32_t sb = __builtin_bit_cast(uint32_t, up ? s1 : s0);
+        const uint32_t out = (sb & 0xFFFFFF80u) | (uint32_t)(up ? j1 : j0);
+        const int x = X0 + lane;
+        if (x < a.W - R) oKeys[((size_t)range * a.H + yout) * a.out_pitch + x] = __builtin_bit_cast(float, out);
+    };
+
+    // ---- warm-up rows: the window fills, nothing is scored, no correction ----
+    const uint32_t zero2[NB] = { 0u, 0u };
+    fetch(yb0 - R);
+    publish(true, yb0 - 1);
+    for (int st = 0; st < 2 * R; st++) {
+        fetch(yb0 - R + st + 1);
+        u32x4_t bop[NB][KS];
+        load_b(bop, zero2, zero2);
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            if (EDGE && !((any_bits >> (t * NB)) & ((1u << NB) - 1u))) continue;
+            u32x4_t aop[KS];
+            load_a(t, aop, 0);
+#pragma unroll
+            for (int c = 0; c < NB; c++)
+                if (!EDGE || ((any_bits >> (t * NB + c)) & 1u)) slide(t, c, aop, bop);
+        }
+        // the row published by the last warm-up step is the first scored one: its statistics go to its slot
+        publish(st + 1 < WN, st + 1 == 2 * R ? yb0 : yb0 - 1);
+    }
+
+    // ---- scored rows ----
+    {
+    uint32_t cprev[NB] = { 0u, 0u };                 // -(256 c, c) of the previous scored row (nothing to take back at the first one)
+    for (int st = 2 * R; st < nsteps; st++) {
+        uint32_t ab = any_bits, pb = part_bits;
+        if (EDGE) asm volatile("" : "+s"(ab), "+s"(pb));        // tested bit by bit where needed, not as a dozen loop-invariant lane masks
+        const int ynew = yb0 - R + st, yout = ynew - R;
+        const float ng[NB] = { fng[0], fng[1] };     // fetched with this row's operands during the previous step
+        uint32_t ccur[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) ccur[c] = cpair(fnc[c]);
+        fetch(ynew + 1);
+        u32x4_t bop[NB][KS];
+        load_b(bop, ccur, cprev);
+#pragma unroll
+        for (int c = 0; c < NB; c++) cprev[c] = ccur[c] ^ 0x80008000u;
         float best[NB] = { NCC_MF_LOW, NCC_MF_LOW };
 #pragma unroll
         for (int t = 0; t < T; t++) {
-            if (!tile_any(t, 0) && !tile_any(t, 1)) continue;
+            if (EDGE && !((ab >> (t * NB)) & ((1u << NB) - 1u))) continue;
             u32x4_t aop[KS];
+            load_a(t, aop, yout);
+            f32x4_t irv[4], qv[4];
 #pragma unroll
-            for (int kk = 0; kk < KS; kk++) aop[kk] = *(const u32x4_t*)(sR + oLane + 32 * t + 8 * kk);
-#pragma unroll
-            for (int c = 0; c < NB; c++) {
-                if (!tile_any(t, c)) continue;
-#pragma unroll
-                for (int kk = 0; kk < KS; kk++)
-                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, aop[kk]),
-                                                                      __builtin_bit_cast(half8_t, bop[c][kk]), acc[t][c], 0, 0, 0);
+            for (int b = 0; b < 4; b++) {
+                irv[b] = *(const f32x4_t*)(sIr + 32 * t + 8 * b + 4 * h);
+                qv[b] = *(const f32x4_t*)(sQ + 32 * t + 8 * b + 4 * h);
             }
-            if (!score) continue;
-            const float sra = sSr[32 * t + n];
-            f32x4_t irv[4];
 #pragma unroll
-            for (int b = 0; b < 4; b++) irv[b] = *(const f32x4_t*)(sIr + 32 * t + 8 * b + 4 * h);
+            for (int c = 0; c < NB; c++)
+                if (!EDGE || ((ab >> (t * NB + c)) & 1u)) slide(t, c, aop, bop);
 #pragma unroll
             for (int c = 0; c < NB; c++) {
-                if (!tile_any(t, c)) continue;
-                const f32x16_t cov = __builtin_amdgcn_mfma_f32_32x32x2f32(sra, nl[c], acc[t][c], 0, 0, 0);
-                float key[16];
-                if (tile_full(t, c)) {
+                if (EDGE && !((ab >> (t * NB + c)) & 1u)) continue;
+                float ir[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) ir[i] = irv[i >> 2][i & 3];
+                if (EDGE && ((pb >> (t * NB + c)) & 1u)) {
+                    // a tile on the edge of the disparity range: 0 <= 32g + (m - n) <= nd - 1 decides per element;
+                    // elements outside get a NaN factor and drop out of the maximum (the empty statement keeps
+                    // the tests inside this rarely taken branch)
+                    int vb = 32 * (T * range + t - c) + 4 * h - n;
+                    asm volatile("" : "+v"(vb));
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        const float sc = cov[i] * irv[i >> 2][i & 3];
-                        key[i] = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, sc) & kmask) | (uint32_t)(16 * t + i));
-                    }
-                } else {
-                    // a tile on the edge of the disparity range: 0 <= 32g + (m - n) <= nd - 1 decides per element
-                    const int vb = 32 * tile_g(t, c) + 4 * h - n;
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const float sc = cov[i] * irv[i >> 2][i & 3];
-                        const float k = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, sc) & kmask) | (uint32_t)(16 * t + i));
                         const bool in = (unsigned)(vb + 8 * (i >> 2) + (i & 3)) <= (unsigned)(nd - 1);
-                        key[i] = in ? k : NCC_MF_LOW;
+                        ir[i] = in ? ir[i] : __builtin_bit_cast(float, qnan);
                     }
                 }
-                float b0 = best[c];
+                // one statement per 4 registers (the compiler pads every asm statement with a wait state of its own):
+                // p = g * (S_R / sigma_R), score = fma(T, 1 / sigma_R, p), key, running maximum
 #pragma unroll
-                for (int i = 0; i < 16; i += 2) b0 = ncc_max3(b0, key[i], key[i + 1]);
-                best[c] = b0;
+                for (int j = 0; j < 4; j++) {
+                    float k0, k1, k2, k3;
+                    asm("v_mul_f32 %1, %9, %10\n\t"
+                        "v_mul_f32 %2, %9, %11\n\t"
+                        "v_mul_f32 %3, %9, %12\n\t"
+                        "v_mul_f32 %4, %9, %13\n\t"
+                        "v_fmac_f32 %1, %5, %14\n\t"
+                        "v_fmac_f32 %2, %6, %15\n\t"
+                        "v_fmac_f32 %3, %7, %16\n\t"
+                        "v_fmac_f32 %4, %8, %17\n\t"
+                        "v_and_or_b32 %1, %1, %18, %19\n\t"
+                        "v_and_or_b32 %2, %2, %18, %20\n\t"
+                        "v_and_or_b32 %3, %3, %18, %21\n\t"
+                        "v_and_or_b32 %4, %4, %18, %22\n\t"
+                        "v_max3_f32 %0, %0, %1, %2\n\t"
+                        "v_max3_f32 %0, %0, %3, %4"
+                        : "+v"(best[c]), "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3)
+                        : "v"(acc[t][c][4 * j]), "v"(acc[t][c][4 * j + 1]), "v"(acc[t][c][4 * j + 2]), "v"(acc[t][c][4 * j + 3]),
+                          "v"(ng[c]), "v"(qv[j][0]), "v"(qv[j][1]), "v"(qv[j][2]), "v"(qv[j][3]),
+                          "v"(ir[4 * j]), "v"(ir[4 * j + 1]), "v"(ir[4 * j + 2]), "v"(ir[4 * j + 3]), "s"(kmask),
+                          "n"(16 * t + 4 * j), "n"(16 * t + 4 * j + 1), "n"(16 * t + 4 * j + 2), "n"(16 * t + 4 * j + 3));
+                }
             }
         }
 
         // single-buffered LDS image: every read of this row was issued above and LDS executes a wavefront's
         // operations in order, so the next row may be written now
-        if (have_next) publish(st + 1 >= 2 * R, st + 1 < WN);
-#pragma unroll
-        for (int c = 0; c < NB; c++) nl[c] = fnl[c];
-
-        if (score) {
-            // the two half-waves hold different right columns of the same left column: bring them together
-            // (lanes 0-31 then own block 0, lanes 32-63 block 1), compare on the 26-bit scores, the larger
-            // right column (lower disparity) keeps a tie
-            float k0 = best[0], k1 = best[1];
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(k0), "+v"(k1));   // k0: lower half-wave's keys, k1: upper's
-            auto jof = [&](float k, int hh) {
-                const uint32_t tg = __builtin_bit_cast(uint32_t, k) & 63u;
-                return (int)(32u * (tg >> 4) + 8u * ((tg >> 2) & 3u) + (tg & 3u)) + 4 * hh;
-            };
-            const int j0 = jof(k0, 0), j1 = jof(k1, 1);
-            const float s0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, k0) & kmask);
-            const float s1 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, k1) & kmask);
-            const bool up = (s1 > s0) || (s1 == s0 && j1 > j0);
-            const uint32_t sb = __builtin_bit_cast(uint32_t, up ? s1 : s0);
-            const uint32_t out = (sb & 0xFFFFFF80u) | (uint32_t)(up ? j1 : j0);
-            const int x = X0 + lane;
-            if (x < a.W - R) oKeys[((size_t)range * a.H + yout) * a.out_pitch + x] = __builtin_bit_cast(float, out);
+        publish(false, yout + 1);
+#ifdef NCC_MF_DEBUG
+        // debug planes: the accumulator and the staged operands of tile 1, block 0, register 6 (right column XR0 + 42 + 4h)
+        if (range == 0 && h == 0) {
+            const size_t o = (size_t)yout * a.out_pitch + X0 + n;
+            oKeys[0 * (size_t)a.H * a.out_pitch + o] = acc[1][0][6];
+            oKeys[1 * (size_t)a.H * a.out_pitch + o] = sIr[32 + n];
+            oKeys[2 * (size_t)a.H * a.out_pitch + o] = sQ[32 + n];
+            oKeys[3 * (size_t)a.H * a.out_pitch + o] = __builtin_bit_cast(float, sC[yout & 1][32 + n]);
+            oKeys[4 * (size_t)a.H * a.out_pitch + o] = ng[0];
+            oKeys[5 * (size_t)a.H * a.out_pitch + o] = __builtin_bit_cast(float, ccur[0]);
         }
+#else
+        emit(best[0], best[1], yout);
+#endif
+    }
     }
 }
