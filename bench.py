@@ -67,16 +67,34 @@ def load_traffic_note(kernel_name, field="bytes"):
 
 
 def issue_floor(W, H, window, nd, kernel_s):
-    """Time the argmax kernel's own instruction mix needs at full vector-issue rate, for the 21x21
-    window: 509 ns of SIMD time per strip row (32 columns x 64 disparities; per-instruction prices
-    measured with tools/ubench/valu_rates on this part, kept in profiles/: dot2c 94, DPP maxima 93,
-    sliding sums 89, packed fmas 86, keys 58, rest 90), 1024 SIMDs, 256- or 128-row bands with 2r
-    warm-up rows."""
+    """Time the argmax kernels' own instruction mix needs at full vector-issue rate.
+
+    Windows up to 21 (matrix-core kernel): a scored wavefront row is 96 accumulator registers per lane, each
+    one v_mul_f32, one v_fmac_f32, one v_and_or_b32 and half a v_max3_f32 (1.05 + 1.05 + 1.8 + 0.9 ns of SIMD
+    time, prices measured with tools/ubench/valu_rates on this part at 8 wavefronts per SIMD, kept in
+    profiles/), plus the issue slots of 18 MFMAs (8 cycles each); a warm-up row is the 18 MFMAs alone
+    (32 cycles each at the 2.1 GHz the kernel holds).  Wavefronts: 64-column blocks x ranges of 96 right
+    columns x bands of rows (the library's rule), 1024 SIMDs.
+    Wider windows (vector kernel, 21x21 figures): 509 ns of SIMD time per strip row of 32 columns x 64
+    disparities (dot2c 94, DPP maxima 93, sliding sums 89, packed fmas 86, keys 58, rest 90)."""
+    r = window // 2
+    rows = H - 2 * r
+    if window <= 21:
+        blocks = -(-(W - 2 * r) // 64)
+        ranges = (((nd + 30) >> 5) + 2 + 2) // 3
+        band = 256
+        while band > 32 and blocks * ranges * -(-rows // band) < 4 * 2048:
+            band //= 2
+        bands = -(-rows // band)
+        scored_ns = 96 * (1.05 + 1.05 + 1.8 + 0.9) + 18 * 8 / 2.1
+        warm_ns = 18 * 32 / 2.1
+        floor_s = blocks * ranges * (rows * scored_ns + bands * 2 * r * warm_ns) * 1e-9 / 1024
+        return {"ms": round(floor_s * 1e3, 3), "frac": round(floor_s / kernel_s, 3) if kernel_s > 0 else None,
+                "note": "vector-issue floor of the matrix-core kernel's instruction mix (prices at 8 wavefronts per SIMD; "
+                        "the kernel's 96 accumulators allow 2) / measured kernel time"}
     if window != 21:
         return None
-    r = window // 2
     strips = -(-(W - 2 * r) // 32)
-    rows = H - 2 * r
     chunks = nd // 64
     band = 256 if strips * -(-rows // 256) * max(chunks, 1) >= 6 * 5120 else 128      # the library's rule
     bands = -(-rows // band)
@@ -84,6 +102,20 @@ def issue_floor(W, H, window, nd, kernel_s):
     floor_s = strip_rows * 509e-9 / 1024
     return {"ms": round(floor_s * 1e3, 3), "frac": round(floor_s / kernel_s, 3) if kernel_s > 0 else None,
             "note": "vector-issue floor of the kernel's instruction mix / measured kernel time"}
+
+
+def mfma_rate(W, H, window, nd, kernel_s):
+    """Matrix-core work of the argmax kernels (windows up to 21): one 32x32x16 f16 product per 8 window taps
+    (the window's taps and two spare ones that carry the mean correction), tile and row: 2 * 16 * KS flop per
+    pixel and disparity, against the dense f16 peak."""
+    if window > 21 or kernel_s <= 0:
+        return None
+    r = window // 2
+    ks = (2 * r + 1 + 2 + 7) // 8
+    flop = 2.0 * 16 * ks * (W - 2 * r) * (H - 2 * r) * nd
+    return {"flop": flop, "achieved_tflops": round(flop / kernel_s / 1e12, 1), "peak_tflops": 2500.0,
+            "frac": round(flop / kernel_s / 2.5e15, 4), "note": "the products are not the bound: the vector unit that turns "
+            "window sums into scores and keys is"}
 
 
 class GatherPipeline:
@@ -520,7 +552,7 @@ def main():
         kernel_s = (main_ms / max(calls, 1)) / 1e3
         alg_bytes = ALG_BYTES_PER_PX_U8 * rows_rank0 * W
         achieved = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-        kname = "ncc_argmax_kernel"
+        kname = "ncc_mfma_argmax_kernel" if args.window <= 21 else "ncc_argmax_kernel"
         wl = ("BASELINE config[1]" if (W, args.window, D) == (8192, 21, 256) else
               "BASELINE config[3] frame size (one of its 16 pairs)" if (W, args.window, D) == (16384, 21, 256) else "non-baseline size")
         result = {
@@ -547,8 +579,11 @@ def main():
                          "algorithmic_bytes": alg_bytes,
                          "valu_busy_frac_pmc": load_traffic_note(kname, "valu_busy"),
                          "issue_floor": issue_floor(W, rows_rank0, args.window, nd, kernel_s) if not strips_mode else None,
+                         "mfma": mfma_rate(W, rows_rank0, args.window, nd, kernel_s),
                          "note": "sliding-window correlation: compulsory HBM traffic is 10 B/px whatever the search "
-                                 "range, the kernel is bound by vector ALU / LDS issue, not by HBM"},
+                                 "range; the window sums slide on the matrix cores (two launches: interior and edge "
+                                 "ranges of right columns, timed together), the kernel is bound by the vector "
+                                 "instructions that turn them into scores and keys, not by HBM"},
         }
         if world == 1 and args.cpu_rows > 0:
             import oracle

@@ -1112,6 +1112,11 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     const size_t plane_px = (size_t)a.H * a.W;
     int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, (size_t)nranges * plane_px * sizeof(float));
     if (rc) return rc;
+    // rows per wavefront: every band re-runs the 2R warm-up rows (a fifth of the cost of a scored row each), so
+    // taller is cheaper as long as the grid still holds several rounds of wavefronts for the chip's 2048 slots
+    a.band_rows = 256;
+    while (a.band_rows > 32 && (long long)nblocks * nranges * ((a.row1 - a.row0 + a.band_rows - 1) / a.band_rows) < 4 * 2048)
+        a.band_rows /= 2;
     a.nbands = (a.row1 - a.row0 + a.band_rows - 1) / a.band_rows;
     mis_prof_mark(ctx);                            // tables done
     {
@@ -1133,14 +1138,6 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     mis_prof_mark(ctx);
     rc = ncc_join(ctx, w);                         // vertical packs, border
     if (rc) return rc;
-#ifdef NCC_MF_DEBUG
-    {
-        const int pa = getenv("MISTEREO_DBG_A") ? atoi(getenv("MISTEREO_DBG_A")) : 0, pb = getenv("MISTEREO_DBG_B") ? atoi(getenv("MISTEREO_DBG_B")) : 1;
-        MIS_HIP(ctx, hipMemcpyAsync(d_disp, w->keys + (size_t)pa * plane_px, plane_px * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        MIS_HIP(ctx, hipMemcpyAsync(d_peak, w->keys + (size_t)pb * plane_px, plane_px * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        return MIS_OK;
-    }
-#endif
     {
         const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
         if (lds > 64 * 1024)

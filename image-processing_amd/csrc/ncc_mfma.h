@@ -398,20 +398,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         // single-buffered LDS image: every read of this row was issued above and LDS executes a wavefront's
         // operations in order, so the next row may be written now
         publish(false, yout + 1);
-#ifdef NCC_MF_DEBUG
-        // debug planes: the accumulator and the staged operands of tile 1, block 0, register 6 (right column XR0 + 42 + 4h)
-        if (range == 0 && h == 0) {
-            const size_t o = (size_t)yout * a.out_pitch + X0 + n;
-            oKeys[0 * (size_t)a.H * a.out_pitch + o] = acc[1][0][6];
-            oKeys[1 * (size_t)a.H * a.out_pitch + o] = sIr[32 + n];
-            oKeys[2 * (size_t)a.H * a.out_pitch + o] = sQ[32 + n];
-            oKeys[3 * (size_t)a.H * a.out_pitch + o] = __builtin_bit_cast(float, sC[yout & 1][32 + n]);
-            oKeys[4 * (size_t)a.H * a.out_pitch + o] = ng[0];
-            oKeys[5 * (size_t)a.H * a.out_pitch + o] = __builtin_bit_cast(float, ccur[0]);
-        }
-#else
         emit(best[0], best[1], yout);
-#endif
     }
     }
 }

@@ -187,6 +187,36 @@ def test_random_shapes_windows_and_ranges(ctx, seed):
     _run(ctx, left, right, window, dmin, dmax)
 
 
+@pytest.mark.parametrize("window", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21])
+def test_every_window_of_the_matrix_core_path(ctx, window):
+    """8-bit windows up to 21 x 21 run the matrix-core argmax kernels.  Search ranges that end on, just before
+    and just past the kernels' 32-disparity tile grid and 96-column ranges, from one disparity to several key
+    planes, on a width that is no multiple of the 64-column blocks."""
+    rng = np.random.default_rng(window)
+    for k, (dmin, dmax) in enumerate([(-16, 16), (0, 0), (-3, 28), (-31, 33), (-100, 92), (5, 200), (-160, 159)]):
+        h, w = 2 * window + 9 + 3 * k, 230 + 17 * k + (dmax - dmin)
+        left = synth.texture(h, w, 77 * window + k)
+        shift = int(rng.integers(dmin, dmax + 1))
+        right = synth.shift_right_image(left, shift, fill_seed=k)
+        st = _run(ctx, left, right, window, dmin, dmax)
+        assert st["valid"] > 0
+
+
+@pytest.mark.parametrize("window", [9, 21])
+def test_extreme_contrast_at_the_accumulator_bound(ctx, window):
+    """Black-and-white images drive the window sums and the mean corrections of the matrix-core kernels to
+    their largest magnitudes (128^2 per pixel): every partial sum must still be exact in f32."""
+    rng = np.random.default_rng(11 + window)
+    h, w = 3 * window + 20, 420
+    base = (rng.integers(0, 2, (h, w + 80)) * 255).astype(np.uint8)
+    base[:, 100:180] = 255                      # saturated run: windows of maximal mean
+    base[: h // 2, 200:260] = 0
+    base[:, 300:330] = np.where(rng.random((h, 30)) < 0.03, 0, 255)      # nearly saturated, small variance
+    left = np.ascontiguousarray(base[:, 40:40 + w])
+    right = np.ascontiguousarray(base[:, 40 + 13:40 + 13 + w])
+    _run(ctx, left, right, window, -64, 64)
+
+
 def test_back_to_back_calls_on_a_caller_stream():
     """The 8-bit path forks small kernels onto an internal stream: three calls enqueued without any
     synchronisation in between (two pairs, output tensors overwritten by the caller's own stream

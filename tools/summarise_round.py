@@ -44,16 +44,20 @@ with open("profiles/%s_pmc_sq.csv" % rnd, "w") as f:
             f.write(k.replace(",", ";") + "," + ",".join("%.4g" % (acc[k][c] / max(cnt[(k, c)], 1)) for c in names) + ",%.3f,%.3f\n" % (vb, la))
 j = {}
 def entry(prefix, label):
+    # all template instances of the kernel that ran (the matrix-core argmax runs as an interior and an edge launch)
     ks = [k for k in res if k.startswith(prefix)]
     if not ks: return
-    k = ks[0]
-    f_, w_ = res[k].get("FETCH_SIZE", 0) * 1024, res[k].get("WRITE_SIZE", 0) * 1024
-    sq = [q for q in acc if q.startswith(prefix)]
+    f_ = sum(res[k].get("FETCH_SIZE", 0) * 1024 for k in ks)
+    w_ = sum(res[k].get("WRITE_SIZE", 0) * 1024 for k in ks)
+    sq = sorted(q for q in acc if q.startswith(prefix))
     vb, la = busy(sq[0]) if sq else (None, None)
     j[label] = {"bytes": f_ + w_, "fetch_bytes_raw": f_, "write_bytes": w_, "source": "profiles/%s_pmc_hbm_traffic.csv" % rnd,
+                "launches_summed": ks,
                 "note": "FETCH_SIZE raw (the gfx950 x2 correction for wide streaming reads is not applied: these kernels read 4 B per lane or scalar)",
                 "valu_busy": round(vb, 3) if vb is not None else None, "lds_active": round(la, 3) if la is not None else None,
+                "valu_busy_of": sq[0] if sq else None,
                 "valu_busy_source": "profiles/%s_pmc_sq.csv" % rnd}
+entry("ncc_mfma_argmax_kernel", "ncc_mfma_argmax_kernel")
 entry("ncc_argmax_kernel", "ncc_argmax_kernel")
 entry("ncc16_argmax_kernel", "ncc16_argmax_kernel")
 # one batch of the FFT tile correlation = one launch of each xc_* kernel
