@@ -25,6 +25,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <cstdlib>
 
 struct NccWs {
     // per-pixel tables, pitch P elements per row, H rows
@@ -49,7 +50,7 @@ struct NccWs {
     // front of it.  ev_fork orders the side stream behind the main one, ev_tables behind the tables,
     // ev_join the refinement behind the side stream.
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_tables = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_tables = nullptr, ev_join = nullptr, ev_main = nullptr;
     bool forked = false;        // the side stream carries work of the current call
     // The tables are built by the first call after a bind and reused by later calls, which may come
     // on another stream (mis_set_stream): ev_built marks the end of the building call on the stream
@@ -72,6 +73,7 @@ static int ncc_fork(mis_ctx* ctx, NccWs* w)
         MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
         MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_tables, hipEventDisableTiming));
         MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
+        MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_main, hipEventDisableTiming));
     }
     MIS_HIP(ctx, hipEventRecord(w->ev_fork, ctx->stream));
     MIS_HIP(ctx, hipStreamWaitEvent(w->side, w->ev_fork, 0));
@@ -107,7 +109,7 @@ void mis_ncc_release(mis_ctx* ctx)
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (w->side) {
         (void)hipStreamSynchronize(w->side);
-        (void)hipEventDestroy(w->ev_fork); (void)hipEventDestroy(w->ev_tables); (void)hipEventDestroy(w->ev_join);
+        (void)hipEventDestroy(w->ev_fork); (void)hipEventDestroy(w->ev_tables); (void)hipEventDestroy(w->ev_join); (void)hipEventDestroy(w->ev_main);
         (void)hipStreamDestroy(w->side);
     }
     if (w->ev_built) (void)hipEventDestroy(w->ev_built);
@@ -1127,17 +1129,26 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
         if (p_hi >= nranges) p_hi = nranges - 1;
         if (p_hi < p_lo) { p_lo = nranges; p_hi = nranges - 1; }      // none
         const int n_in = p_hi - p_lo + 1, n_edge = nranges - n_in;
-        // the edge ranges first: their wavefronts take longer, the interior ones fill the machine behind them
+        // the edge ranges go to the side stream (behind the tables of both images): the two launches share the
+        // machine instead of running one after the other, each with a tail of its own
+        hipStream_t se = ctx->stream;
+        if (n_edge > 0 && n_in > 0) {
+            rc = ncc_fork(ctx, w);
+            if (rc) return rc;
+            MIS_HIP(ctx, hipEventRecord(w->ev_main, ctx->stream));
+            MIS_HIP(ctx, hipStreamWaitEvent(w->side, w->ev_main, 0));
+            se = w->side;
+        }
         if (n_edge > 0)
-            hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, true>), dim3((unsigned)(nblocks * a.nbands * n_edge)), dim3(64), 0, ctx->stream,
+            hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, true>), dim3((unsigned)(nblocks * a.nbands * n_edge)), dim3(64), 0, se,
                                a, nblocks, n_edge, n_in > 0 ? p_lo : nranges, p_hi + 1, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
         if (n_in > 0)
             hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, false>), dim3((unsigned)(nblocks * a.nbands * n_in)), dim3(64), 0, ctx->stream,
                                a, nblocks, n_in, p_lo, 0, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
     }
-    mis_prof_mark(ctx);
-    rc = ncc_join(ctx, w);                         // vertical packs, border
+    rc = ncc_join(ctx, w);                         // vertical packs, border, edge ranges
     if (rc) return rc;
+    mis_prof_mark(ctx);
     {
         const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
         if (lds > 64 * 1024)
