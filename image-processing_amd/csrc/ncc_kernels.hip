@@ -713,17 +713,18 @@ struct NccRefineCfg {
 // chunk contributes its second plane, which also leaves out the neighbour's lane 1 (or 62), i.e. the
 // disparity two away from the winner, whose exact score is then computed here like the winner's.
 // Key values carry 26 bits of the score (relative error below 8e-6).
-template <int R, bool WANT2>
+// MF: key planes of the matrix-core kernels (a range of 32*NCC_MF_T right columns per plane, 25-bit score, column
+// index in the range below) instead of the vector kernel's (a chunk of 64 disparities per plane, 26-bit score,
+// 63 - lane below)
+template <int R, bool WANT2, bool MF>
 __global__ __launch_bounds__(512) void ncc_refine_kernel(
     NccArgs a, const uint32_t* __restrict__ VL, const uint32_t* __restrict__ VR,
     const float* __restrict__ gNegc, const float* __restrict__ gNegg, const float* __restrict__ gIL,
     const float* __restrict__ gRsr, const float* __restrict__ gRir, const float* __restrict__ gKeys, int nchunk,
     float* __restrict__ oDisp, float* __restrict__ oPeak, int16_t* __restrict__ oIdisp,
-    const float* __restrict__ gKeys2, float* __restrict__ oPeak2, int range_tiles)
+    const float* __restrict__ gKeys2, float* __restrict__ oPeak2)
 {
-    // range_tiles == 0: planes of the vector argmax kernel (chunk of 64 disparities per plane, 26-bit score,
-    // 63 - lane below); > 0: planes of the matrix-core kernel (range of 32*range_tiles right columns per
-    // plane, 25-bit score, column index in the range below)
+    constexpr int range_tiles = MF ? NCC_MF_T : 0;
     using Cfg = NccRefineCfg<R>;
     constexpr int NQ = Cfg::NQ, LC = Cfg::LC;
     extern __shared__ __attribute__((aligned(16))) uint32_t ncc_refine_lds[];
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     const size_t plane = (size_t)a.H * a.out_pitch;
     if (inside) {
         float best = -1.0e30f;                     // below any score, above the bias of masked lanes
-        constexpr int NKB = NCC_REFINE_KEY_BATCH;  // planes per round trip (independent loads)
+        constexpr int NKB = MF ? 6 : NCC_REFINE_KEY_BATCH;  // planes per round trip (independent loads; +-256 is 6 ranges or 9 chunks)
         for (int c0 = 0; c0 < nchunk; c0 += NKB) {
             float k4[NKB];
 #pragma unroll
@@ -1092,11 +1093,11 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     {
         const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
         if (lds > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, WANT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((ncc_refine_kernel<R, WANT2>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, WANT2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ncc_refine_kernel<R, WANT2, false>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
                            lds, ctx->stream,
                            a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nplanes, d_disp, d_peak, d_idisp,
-                           keys2, d_peak2, 0);
+                           keys2, d_peak2);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
@@ -1152,11 +1153,11 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     {
         const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
         if (lds > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((ncc_refine_kernel<R, false>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ncc_refine_kernel<R, false, true>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
                            lds, ctx->stream,
                            a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nranges, d_disp, d_peak, d_idisp,
-                           (const float*)nullptr, (float*)nullptr, NCC_MF_T);
+                           (const float*)nullptr, (float*)nullptr);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
