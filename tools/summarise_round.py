@@ -53,7 +53,7 @@ def entry(prefix, label):
     vb, la = busy(sq[0]) if sq else (None, None)
     j[label] = {"bytes": f_ + w_, "fetch_bytes_raw": f_, "write_bytes": w_, "source": "profiles/%s_pmc_hbm_traffic.csv" % rnd,
                 "launches_summed": ks,
-                "note": "FETCH_SIZE raw (the gfx950 x2 correction for wide streaming reads is not applied: these kernels read 4 B per lane or scalar)",
+                "note": "FETCH_SIZE raw: the gfx950 x2 correction for 16-byte-per-lane streaming reads is not applied (the vector kernels read 4 B per lane or scalar; the matrix-core kernels stage their rows with 16-byte loads out of the L2, so their fetch figure may be low by up to 2x)",
                 "valu_busy": round(vb, 3) if vb is not None else None, "lds_active": round(la, 3) if la is not None else None,
                 "valu_busy_of": sq[0] if sq else None,
                 "valu_busy_source": "profiles/%s_pmc_sq.csv" % rnd}
