@@ -1,0 +1,78 @@
+"""Randomised parity stress of the dense NCC (8-bit, windows 3..21: the matrix-core kernels; wider windows and
+16-bit: the vector kernels) against the CPU oracle, beyond the cases the test-suite pins:
+   python tools/stress_ncc.py [cases] [seed]
+Every case: random frame shape, window, search range, shift, optional row strip; prints a line per failure."""
+import os, sys
+R0 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [R0 + '/image-processing_amd', R0 + '/oracle', R0 + '/tests']
+import numpy as np, torch
+import mistereo, oracle, synth
+from ncc_util import compare_ncc, flat_mask
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ctx = mistereo.Context(0)
+bad = 0
+for k in range(cases):
+    rng = np.random.default_rng(seed0 * 100003 + k)
+    window = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 21, 21, 23, 31]))
+    nd = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 95, 96, 97, 128, 129, 160, 200, 257, 300, 513]))
+    dmin = int(rng.integers(-nd, 40))
+    dmax = dmin + nd - 1
+    h = int(rng.integers(window, window + 70))
+    w = int(rng.integers(max(window, 20), 420))
+    if rng.random() < 0.2:
+        w = int(rng.choice([64, 65, 127, 128, 129, 192, 256])) + 2 * (window // 2)
+    left = synth.texture(h, w, 7000 + k)
+    shift = int(rng.integers(dmin, dmax + 1))
+    right = synth.shift_right_image(left, shift, fill_seed=k)
+    if rng.random() < 0.25:
+        left[h // 4: h // 2, w // 5: w // 2] = int(rng.integers(0, 256))      # flat patch
+    if rng.random() < 0.15:
+        right = (rng.integers(0, 2, right.shape) * 255).astype(np.uint8)      # extreme contrast
+    try:
+        ctx.upload_pair(left, right)
+        if rng.random() < 0.4 and h > window + 3:
+            # a row strip computed on its own must equal the oracle's rows
+            row0 = int(rng.integers(0, h - 1)); nrows = int(rng.integers(1, h - row0 + 1))
+            tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+            ctx.bind_pair_torch(tl, tr)
+            d = torch.full((h, w), -7.0, device="cuda"); p = torch.full((h, w), -7.0, device="cuda")
+            i = torch.full((h, w), -7, device="cuda", dtype=torch.int16)
+            torch.cuda.synchronize()
+            ctx.ncc_dense_torch(window, dmin, dmax, d, p, i, row0=row0, nrows=nrows)
+            ctx.synchronize()
+            gpu = {"disp": d.cpu().numpy()[row0:row0 + nrows], "peak": p.cpu().numpy()[row0:row0 + nrows], "idisp": i.cpu().numpy()[row0:row0 + nrows]}
+            assert torch.all(d[:row0] == -7.0) and torch.all(d[row0 + nrows:] == -7.0), "rows outside the strip were written"
+            ora = oracle.ncc_dense(left, right, window, dmin, dmax, want_volume=True)
+            ora["flat"] = flat_mask(ora["volume"], ora["idisp"], dmin)
+            sl = slice(row0, row0 + nrows)
+            ora = {k2: (v[sl] if isinstance(v, np.ndarray) and v.shape[:1] == (h,) else v) for k2, v in ora.items()}
+        else:
+            gpu = ctx.ncc_dense(window, dmin, dmax, want_idisp=True)
+            ora = oracle.ncc_dense(left, right, window, dmin, dmax, want_volume=True)
+            ora["flat"] = flat_mask(ora["volume"], ora["idisp"], dmin)
+        try:
+            compare_ncc(gpu, ora, volume=ora["volume"], dmin=dmin)
+        except AssertionError as e:
+            # frames of a few hundred pixels miss the suite's 99.9 % agreement bar with two or three near-ties:
+            # here every difference must be a near-tie in the oracle's volume and there must be few of them
+            if "integer argmax agrees" not in str(e):
+                raise
+            gi, oi = gpu["idisp"].astype(np.int64), ora["idisp"].astype(np.int64)
+            ys, xs = np.nonzero(gi != oi)
+            vol = ora["volume"]
+            so = vol[ys, xs, oi[ys, xs] - dmin]
+            gap = np.abs(vol[ys, xs, gi[ys, xs] - dmin] - so)
+            # exact ties between NEGATIVE best scores (no candidate correlates) go to the higher disparity on the GPU:
+            # a declared deviation, counted apart
+            declared = (gap == 0) & (so < 0)
+            assert (~declared).sum() <= max(3, 0.002 * (oi != -32768).sum()) and np.all(gap <= 2e-5), \
+                "%d argmax differences (%d exact ties of negative scores), largest score gap %g" % (len(ys), declared.sum(), gap.max())
+    except AssertionError as e:
+        bad += 1
+        print("FAIL case", k, dict(window=window, dmin=dmin, dmax=dmax, h=h, w=w, shift=shift), str(e)[:200], flush=True)
+    if k % 50 == 49:
+        print("...", k + 1, "cases,", bad, "failures", flush=True)
+print("done:", cases, "cases,", bad, "failures")
+sys.exit(1 if bad else 0)
