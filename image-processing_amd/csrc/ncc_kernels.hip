@@ -7,7 +7,12 @@
 // (image3.cpp:775-811) and names as a TODO (image3.cpp:866-870); sign and tie-break follow
 // image3.cpp:696-699 and image3.cpp:486-501.
 //
-// Mapping onto the machine
+// Two argmax paths feed one refinement kernel.  Windows up to 21 x 21 (without the second-peak output) run on
+// the matrix cores: ncc_mfma.h, where the window sums of 32 x 32 tiles of (left column, right column) pairs slide
+// down the rows as MFMA accumulators.  Wider windows and calls that ask for the second peak run the vector
+// kernels of this file:
+//
+// Mapping onto the machine (vector kernels)
 //   lane        <-> disparity (64 consecutive d per wavefront, one "chunk")
 //   wavefront   <-> one chunk of disparities for a strip of WT pixel columns, walking down a band of rows
 //   workgroup   <-> one wavefront; wavefronts never synchronise with each other
@@ -38,7 +43,7 @@ struct NccWs {
     float* Rir = nullptr;       // 1/sqrt(sum (R-mean)^2), 0 when flat, NaN where the window does not fit
     uint32_t* VL = nullptr;     // [ceil(H/4)][pitch]: 4 vertically adjacent pixels, (p-128) as int8 each
     uint32_t* VR = nullptr;
-    float* keys = nullptr;      // [chunks][H][W] best key per pixel and chunk of 64 disparities
+    float* keys = nullptr;      // [planes][H][W] best key per pixel and chunk of 64 disparities (vector kernels) or range of 96 right columns (matrix-core kernels)
     size_t keys_bytes = 0;
     size_t cap_px = 0;          // capacity in pixels (pitch*rows) of the arrays above
     int pitch = 0, rows = 0;
