@@ -202,6 +202,17 @@ def test_every_window_of_the_matrix_core_path(ctx, window):
         assert st["valid"] > 0
 
 
+def test_widest_search_range_on_the_matrix_core_path(ctx):
+    """2048 disparities (the API's limit) are 22 key planes of 96 right columns; the frame is narrower than the range,
+    so most candidates of most pixels fall off the raster."""
+    left = synth.texture(44, 1500, 4242)
+    right = synth.shift_right_image(left, -333, fill_seed=5)
+    st = _run(ctx, left, right, 21, -1024, 1023)
+    assert st["valid"] > 0
+    right = synth.shift_right_image(left, 700, fill_seed=6)
+    _run(ctx, left, right, 11, 0, 2047)
+
+
 @pytest.mark.parametrize("window", [9, 21])
 def test_extreme_contrast_at_the_accumulator_bound(ctx, window):
     """Black-and-white images drive the window sums and the mean corrections of the matrix-core kernels to
