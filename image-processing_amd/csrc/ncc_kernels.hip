@@ -125,94 +125,108 @@ void mis_ncc_release(mis_ctx* ctx)
 // ---------------------------------------------------------------------------------------------
 // Pre-pass 1: window statistics and the packed row pairs, one pass over the raster.
 // A workgroup owns 256 columns and a band of rows.  It walks down the band (plus r rows above and
-// below): each row is staged in LDS (p' = p - 128), every thread sums its column's horizontal
-// window of p' and p'^2, keeps the last 2r+1 such row sums in an LDS ring (a thread only touches
-// its own ring column) and slides the vertical window over them.  |sum p'| < 2^12 and
-// sum p'^2 < 2^19 for windows up to 31, so a ring entry is one 32-bit word.
+// below): each row is staged in LDS as one word per pixel, (p'^2 << 13) | (p' + 128) with p' = p - 128,
+// so that one integer add per tap sums p' and p'^2 together (31 taps: the low field stays below 2^13,
+// the high one below 2^19).  Every thread sums its column's horizontal window, keeps the last 2r+1 such
+// row sums in an LDS ring (a thread only touches its own ring column) and slides the vertical window
+// over them.
 // ---------------------------------------------------------------------------------------------
 #define NCC_STATS_BAND 64
-template <typename T, bool LEFT>
+template <typename T, bool LEFT, int R>
 __global__ __launch_bounds__(256) void ncc_tables_kernel(const T* __restrict__ img, size_t stride_px,
-                                                         int W, int H, int r, int pitch, int band0,
+                                                         int W, int H, int pitch, int band0,
                                                          uint32_t* __restrict__ pack,
                                                          float* __restrict__ o0,   // LEFT: negc   RIGHT: S_R
                                                          float* __restrict__ o1,   // LEFT: negg   RIGHT: iR
                                                          float* __restrict__ o2)   // LEFT: iL
 {
-    __shared__ int rowbuf[2][256 + 32];
-    __shared__ uint32_t ring[31][256];
+    constexpr int r = R, Wn = 2 * R + 1;
+    constexpr long long N = (long long)Wn * Wn;
+    __shared__ uint32_t rowbuf[2][256 + 32];
+    __shared__ uint32_t ring[Wn][256];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * 256, x = x0 + tid;
     const int y0 = (band0 + blockIdx.y) * NCC_STATS_BAND;      // the launch covers bands band0 .. band0 + gridDim.y - 1
     const int y1 = min(y0 + NCC_STATS_BAND, H);
-    const int Wn = 2 * r + 1;
-    const long long N = (long long)Wn * Wn;
     const bool colok = (x >= r && x < W - r);
-    int s1 = 0, s2 = 0;                 // vertical sums of the ring: rows yy-2r .. yy
+    uint32_t s1 = 0, s2 = 0;            // vertical sums of the ring, rows yy-2r .. yy: of (p' + 128) and of p'^2
     int slot = 0;
-    // A row is fetched into registers one iteration ahead and published to LDS after the arithmetic.
-    // Every load of an iteration is issued unconditionally at its top (coordinates clamped into the
-    // raster, the value replaced afterwards where the pixel does not exist): a load inside a
-    // conditional block is waited for at the end of that block, which turns the walk down the band
-    // into one exposed memory round trip per row.
+    // Rows are fetched into registers two iterations ahead and published to LDS one iteration ahead,
+    // after the arithmetic.  Every load of an iteration is issued unconditionally at its top (coordinates
+    // clamped into the raster, the value replaced afterwards where the pixel does not exist): a load
+    // inside a conditional block is waited for at the end of that block, which turns the walk down the
+    // band into one exposed memory round trip per row.
     const int Wm = W - 1, Hm = H - 1;
+    // the fetched value stays as loaded until it is used: arithmetic on it here would be scheduled right behind
+    // the load and wait for it
     auto raw = [&](int yy, int xs) -> int {
-        return (int)img[(size_t)min(max(yy, 0), Hm) * stride_px + min(max(xs, 0), Wm)] - 128;
+        return (int)img[(size_t)min(max(yy, 0), Hm) * stride_px + min(max(xs, 0), Wm)];
     };
     auto inside = [&](int yy, int xs) -> bool { return yy >= 0 && yy < H && xs >= 0 && xs < W; };
+    auto word = [&](int v) -> uint32_t { return ((uint32_t)__mul24(v, v) << 13) | (uint32_t)(v + 128); };
     const int xa = x0 - r + tid, xb = x0 - r + 256 + (tid & 31);   // staged columns of this thread (xb: halo, threads 0..31)
+    const bool halo = tid < 2 * r;
+    struct Row { int n0, n1, pa, pb; };
+    // fetch(yy): the staged pixels of row yy + 1 and, for the packed pair written at iteration yy, the own
+    // pixel of row yy - r and the one Wn rows above it
+    auto fetch = [&](int yy, int z) -> Row { return Row{ raw(yy + 1, xa + z), raw(yy + 1, xb + z), raw(yy - r, x + z), raw(yy - r - Wn, x + z) }; };
+    const int ya = y0 - r, yz = y1 + r;
     {
-        const int v0 = raw(y0 - r, xa), v1 = raw(y0 - r, xb);
-        rowbuf[0][tid] = inside(y0 - r, xa) ? v0 : 0;
-        if (tid < 32) rowbuf[0][256 + tid] = (inside(y0 - r, xb) && tid < 2 * r) ? v1 : 0;
+        const int v0 = raw(ya, xa), v1 = raw(ya, xb);
+        rowbuf[0][tid] = word(inside(ya, xa) ? v0 - 128 : 0);
+        if (tid < 32) rowbuf[0][256 + tid] = word((inside(ya, xb) && halo) ? v1 - 128 : 0);
     }
+    Row f0 = fetch(ya, 0), f1 = fetch(ya + 1, 0);
     __syncthreads();
-    for (int yy = y0 - r; yy < y1 + r; yy++) {
-        const int buf = (yy - (y0 - r)) & 1;
-        const bool more = (yy + 1 < y1 + r);
-        int nxt0 = raw(yy + 1, xa), nxt1 = raw(yy + 1, xb);
-        int pa = raw(yy - r, x), pb = raw(yy - r - Wn, x);          // own pixel and the one Wn rows above, for the packed pair
-        int h1 = 0, h2 = 0;
-        for (int i = 0; i <= 2 * r; i++) { const int v = rowbuf[buf][tid + i]; h1 += v; h2 += v * v; }
-        if (yy - (y0 - r) >= Wn) {      // the ring is full: drop the row that leaves the window
+    auto step = [&](int yy, Row& cur) {             // cur: fetched two iterations ago, refilled here for iteration yy + 2
+        const int buf = (yy - ya) & 1;
+        // everything that depends on the fetched bytes is derived first, so that the refill can land in
+        // the same registers and nothing waits for it before the iteration after next
+        uint32_t w0 = word(inside(yy + 1, xa) ? cur.n0 - 128 : 0);
+        uint32_t w1 = word((inside(yy + 1, xb) && halo) ? cur.n1 - 128 : 0);
+        float pa = (x < W) ? (float)(cur.pa - 128) : 0.f;
+        float pb = (x < W && yy - r - Wn >= 0) ? (float)(cur.pb - 128) : 0.f;
+        int z = 0;                      // the refill's addresses hang on this statement: it is issued after the lines above
+        asm volatile("" : "+v"(z), "+v"(w0), "+v"(w1), "+v"(pa), "+v"(pb));
+        cur = fetch(yy + 2, z);
+        uint32_t hs = 0;
+#pragma unroll
+        for (int i = 0; i < Wn; i++) hs += rowbuf[buf][tid + i];
+        if (yy - ya >= Wn) {            // the ring is full: drop the row that leaves the window
             const uint32_t old = ring[slot][tid];
-            s1 -= (int)(old >> 19) - 4096;
-            s2 -= (int)(old & 0x7FFFFu);
+            s1 -= old & 0x1FFFu;
+            s2 -= old >> 13;
         }
-        ring[slot][tid] = ((uint32_t)(h1 + 4096) << 19) | (uint32_t)h2;
+        ring[slot][tid] = hs;
         slot = (slot + 1 == Wn) ? 0 : slot + 1;
-        s1 += h1; s2 += h2;
+        s1 += hs & 0x1FFFu; s2 += hs >> 13;
 
-        asm volatile("" : "+v"(nxt0), "+v"(nxt1), "+v"(pa), "+v"(pb));     // the loads stay above the arithmetic
-        nxt0 = inside(yy + 1, xa) ? nxt0 : 0;
-        nxt1 = (inside(yy + 1, xb) && tid < 2 * r) ? nxt1 : 0;
         const int y = yy - r;           // the window centred at y is complete now
-        if (y >= y0 && x < pitch) {
+        if (y >= y0 && y < y1 && x < pitch) {
             const size_t o = (size_t)y * pitch + x;
             // packed pair: this row and the row Wn above
-            const float a = (x < W) ? (float)pa : 0.f;
-            const float b = (x < W && y - Wn >= 0) ? (float)pb : 0.f;
             half2_t h;
-            h.x = (_Float16)a;
-            h.y = (_Float16)(LEFT ? -b : b);
+            h.x = (_Float16)pa;
+            h.y = (_Float16)(LEFT ? -pb : pb);
             pack[o] = __builtin_bit_cast(uint32_t, h);
 
             const bool rowok = (y >= r && y < H - r);
             float v0 = 0.f, v1 = LEFT ? 0.f : (colok ? 0.f : __builtin_nanf("")), v2 = 0.f;
             if (colok && rowok) {
-                const long long var = N * (long long)s2 - (long long)s1 * s1;   // N * sum (p-mean)^2, exact
+                const int t1 = (int)s1 - 128 * (int)N;                          // sum of p'
+                const long long var = N * (long long)s2 - (long long)t1 * t1;   // N * sum (p-mean)^2, exact
                 // 1/sigma to float accuracy (a few ulp): scores only need 1e-7 relative
                 const float inv = var > 0 ? sqrtf((float)N / (float)var) : 0.f;
                 if (LEFT) {
-                    // c: the integer nearest to s1/N (N is odd, so there are no ties; float division is
+                    // c: the integer nearest to t1/N (N is odd, so there are no ties; float division is
                     // accurate enough to pick it, and the remainder below is exact whatever c is)
-                    const int c = (int)__builtin_rintf((float)s1 / (float)N);
-                    const int rem = s1 - (int)N * c;
-                    v0 = -(float)c;
+                    const int cc = (int)__builtin_rintf((float)t1 / (float)N);
+                    const int rem = t1 - (int)N * cc;
+                    v0 = -(float)cc;
                     v1 = -((float)rem / (float)N);
                     v2 = inv;
                 } else {
-                    v0 = (float)s1;
+                    v0 = (float)t1;
                     v1 = inv;
                 }
             }
@@ -226,8 +240,15 @@ __global__ __launch_bounds__(256) void ncc_tables_kernel(const T* __restrict__ i
                 o1[o] = v1;
             }
         }
-        if (more) { rowbuf[buf ^ 1][tid] = nxt0; if (tid < 32) rowbuf[buf ^ 1][256 + tid] = nxt1; }
+        if (yy + 1 < yz) {
+            rowbuf[buf ^ 1][tid] = w0;
+            if (tid < 32) rowbuf[buf ^ 1][256 + tid] = w1;
+        }
         __syncthreads();                // the next row is staged, this row's buffer may be overwritten
+    };
+    for (int yy = ya; yy < yz; yy += 2) {
+        step(yy, f0);
+        step(yy + 1, f1);               // unconditional (a conditional refill costs register copies that wait for the loads); with an odd row count the last call writes nothing
     }
 }
 
@@ -976,6 +997,20 @@ __global__ __launch_bounds__(256) void ncc_border_kernel(float* disp, float* pea
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
+template <bool LEFT>
+static void ncc_launch_tables(int r, dim3 grid, hipStream_t s, const uint8_t* img, size_t stride_px, int W, int H, int pitch,
+                              int band0, uint32_t* pack, float* o0, float* o1, float* o2)
+{
+#define NCC_TCASE(RR) case RR: hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, LEFT, RR>), grid, dim3(256), 0, s, img, stride_px, \
+                                                  W, H, pitch, band0, pack, o0, o1, o2); break;
+    switch (r) {
+        NCC_TCASE(1) NCC_TCASE(2) NCC_TCASE(3) NCC_TCASE(4) NCC_TCASE(5) NCC_TCASE(6) NCC_TCASE(7) NCC_TCASE(8)
+        NCC_TCASE(9) NCC_TCASE(10) NCC_TCASE(11) NCC_TCASE(12) NCC_TCASE(13) NCC_TCASE(14) NCC_TCASE(15)
+        default: break;                 // ncc_run rejects other windows before anything is launched
+    }
+#undef NCC_TCASE
+}
+
 // Builds (or reuses) the per-pair tables for raster rows [need_lo, need_hi): the rows the correlation of
 // the requested output rows reads.  The tables of rows built by earlier calls on the same pair are kept,
 // so a frame computed strip by strip builds every band of rows once, and a rank that computes one strip
@@ -1036,15 +1071,13 @@ static int ncc_prepare(mis_ctx* ctx, int window, bool use_side, int need_lo, int
     for (int k = 0; k < nparts; k++) {
         const int band0 = lo[k] / NCC_STATS_BAND;
         const dim3 sgrid((pitch + 255) / 256, (hi[k] - lo[k] + NCC_STATS_BAND - 1) / NCC_STATS_BAND);
-        hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, false>), sgrid, block, 0, sv, pr, ctx->stride, W, H, r, pitch, band0,
-                           w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
+        ncc_launch_tables<false>(r, sgrid, sv, pr, ctx->stride, W, H, pitch, band0, w->Rpack, w->Rsr, w->Rir, (float*)nullptr);
     }
     if (use_side) MIS_HIP(ctx, hipEventRecord(w->ev_tables, w->side));
     for (int k = 0; k < nparts; k++) {
         const int band0 = lo[k] / NCC_STATS_BAND;
         const dim3 sgrid((pitch + 255) / 256, (hi[k] - lo[k] + NCC_STATS_BAND - 1) / NCC_STATS_BAND);
-        hipLaunchKernelGGL((ncc_tables_kernel<uint8_t, true>), sgrid, block, 0, s, pl, ctx->stride, W, H, r, pitch, band0,
-                           w->Lpack, w->negc, w->negg, w->iL);
+        ncc_launch_tables<true>(r, sgrid, s, pl, ctx->stride, W, H, pitch, band0, w->Lpack, w->negc, w->negg, w->iL);
     }
     if (use_side) MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, w->ev_tables, 0));
     for (int k = 0; k < nparts; k++) {
