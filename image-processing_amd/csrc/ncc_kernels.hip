@@ -7,10 +7,9 @@
 // (image3.cpp:775-811) and names as a TODO (image3.cpp:866-870); sign and tie-break follow
 // image3.cpp:696-699 and image3.cpp:486-501.
 //
-// Two argmax paths feed one refinement kernel.  Windows up to 21 x 21 (without the second-peak output) run on
-// the matrix cores: ncc_mfma.h, where the window sums of 32 x 32 tiles of (left column, right column) pairs slide
-// down the rows as MFMA accumulators.  Wider windows and calls that ask for the second peak run the vector
-// kernels of this file:
+// Two argmax paths feed one refinement kernel.  Windows up to 21 x 21 run on the matrix cores: ncc_mfma.h, where
+// the window sums of 32 x 32 tiles of (left column, right column) pairs slide down the rows as MFMA accumulators.
+// Wider windows run the vector kernels of this file:
 //
 // Mapping onto the machine (vector kernels)
 //   lane        <-> disparity (64 consecutive d per wavefront, one "chunk")
@@ -941,7 +940,24 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
             if (oIdisp) oIdisp[o] = (int16_t)ds;
         }
     }
-    if (WANT2) {
+    if constexpr (WANT2 && MF) {
+        // plane p holds right columns 96 p + j of the run that starts at disparity dmax + ((x - R) & 63): a higher
+        // plane or j is a lower disparity.  The winner's plane gives its second key; a neighbouring plane whose best
+        // is the winner's neighbour across the plane boundary (j = 95 before j = 0) gives its second key too, which
+        // also leaves out the column two away from the winner: that one's exact score is computed below.
+        constexpr int RW = 32 * range_tiles;
+        const int tt = a.dmax + ((x - R) & 63) - ds, ps = tt / RW, js = tt % RW;
+        for (int c = 0; c < nchunk; c++) {
+            const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * plane + o]);
+            const int jr = (int)(kb & 127u);
+            bool second_plane = (c == ps);
+            if (c == ps - 1 && js == 0 && jr == RW - 1) { second_plane = true; xd = 2; }
+            if (c == ps + 1 && js == RW - 1 && jr == 0) { second_plane = true; xd = -2; }
+            const uint32_t vb = second_plane ? __builtin_bit_cast(uint32_t, gKeys2[(size_t)c * plane + o]) : kb;
+            const float v = __builtin_bit_cast(float, vb & 0xFFFFFF80u);
+            if (v > sec) sec = v;
+        }
+    } else if (WANT2) {
         const int bc = (ds - a.dmin) >> 6, lw = (ds - a.dmin) & 63;
         for (int c = 0; c < nchunk; c++) {
             const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * plane + o]);
@@ -1143,16 +1159,17 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
 
 // Matrix-core path: one key plane per range of 32*NCC_MF_T right columns, no tail kernel (the tiles on the
 // edge of the disparity range are masked per element).
-template <int R>
-static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp)
+template <int R, bool WANT2>
+static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
 {
     NccWs* w = ctx->ncc;
     const int nd = a.dmax - a.dmin + 1;
     const int nranges = NccMfCfg<R>::ranges(nd);
     const int nblocks = (a.W - 2 * R + 63) / 64;
     const size_t plane_px = (size_t)a.H * a.W;
-    int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, (size_t)nranges * plane_px * sizeof(float));
+    int rc = mis_reserve(ctx, (void**)&w->keys, &w->keys_bytes, (size_t)nranges * plane_px * sizeof(float) * (WANT2 ? 2 : 1));
     if (rc) return rc;
+    float* keys2 = WANT2 ? w->keys + (size_t)nranges * plane_px : nullptr;      // second-peak planes behind the first ones
     // rows per wavefront: every band re-runs the 2R warm-up rows (a fifth of the cost of a scored row each), so
     // taller is cheaper as long as the grid still holds several rounds of wavefronts for the chip's 2048 slots
     a.band_rows = 256;
@@ -1179,11 +1196,11 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
             se = w->side;
         }
         if (n_edge > 0)
-            hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, true>), dim3((unsigned)(nblocks * a.nbands * n_edge)), dim3(64), 0, se,
-                               a, nblocks, n_edge, n_in > 0 ? p_lo : nranges, p_hi + 1, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+            hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, true, WANT2>), dim3((unsigned)(nblocks * a.nbands * n_edge)), dim3(64), 0, se,
+                               a, nblocks, n_edge, n_in > 0 ? p_lo : nranges, p_hi + 1, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys, keys2);
         if (n_in > 0)
-            hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, false>), dim3((unsigned)(nblocks * a.nbands * n_in)), dim3(64), 0, ctx->stream,
-                               a, nblocks, n_in, p_lo, 0, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+            hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, false, WANT2>), dim3((unsigned)(nblocks * a.nbands * n_in)), dim3(64), 0, ctx->stream,
+                               a, nblocks, n_in, p_lo, 0, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys, keys2);
     }
     rc = ncc_join(ctx, w);                         // vertical packs, border, edge ranges
     if (rc) return rc;
@@ -1191,11 +1208,11 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     {
         const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
         if (lds > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((ncc_refine_kernel<R, false, true>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, WANT2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ncc_refine_kernel<R, WANT2, true>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
                            lds, ctx->stream,
                            a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nranges, d_disp, d_peak, d_idisp,
-                           (const float*)nullptr, (float*)nullptr);
+                           keys2, d_peak2);
     }
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
@@ -1285,12 +1302,14 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     }
     a.nchunk = total_chunks;
     static const int mfma_env = [] { const char* e = getenv("MISTEREO_NCC_MFMA"); return e ? atoi(e) : 1; }();
-    const bool use_mfma = (mfma_env != 0 && !d_peak2 && r <= NCC_MF_MAX_R);
+    const bool use_mfma = (mfma_env != 0 && r <= NCC_MF_MAX_R);
     // wavefronts per SIMD the register budget is set for: 5 up to 23 x 23 windows, 4 beyond; the
     // second-peak variant keeps 16 more keys in registers: 4 wavefronts for every window
 #define NCC_MW(RR) ((RR) <= 11 ? 5 : 4)
-#define NCC_CASE(RR) case RR: rc = d_peak2 ? ncc_launch_fast<RR, 32, 4, true>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
-                               : use_mfma ? ncc_launch_mfma<(RR <= NCC_MF_MAX_R ? RR : NCC_MF_MAX_R)>(ctx, a, d_disp, d_peak, d_idisp) \
+#define NCC_MR(RR) ((RR) <= NCC_MF_MAX_R ? (RR) : NCC_MF_MAX_R)
+#define NCC_CASE(RR) case RR: rc = use_mfma ? (d_peak2 ? ncc_launch_mfma<NCC_MR(RR), true>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
+                                                       : ncc_launch_mfma<NCC_MR(RR), false>(ctx, a, d_disp, d_peak, d_idisp, nullptr)) \
+                               : d_peak2 ? ncc_launch_fast<RR, 32, 4, true>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
                                : ncc_launch_fast<RR, 32, NCC_MW(RR), false>(ctx, a, d_disp, d_peak, d_idisp, nullptr); break;
     switch (r) {
         NCC_CASE(1) NCC_CASE(2) NCC_CASE(3) NCC_CASE(4) NCC_CASE(5) NCC_CASE(6) NCC_CASE(7) NCC_CASE(8)

@@ -31,7 +31,8 @@
 // pixel each (ds_read_b128 of 4 consecutive pixels = 8 consecutive k needs 16-byte alignment).
 //
 // Output: one key plane per range of right columns: upper 25 bits of the best score, below them the
-// right column's index j in the range (d = dmax + ((x - r) & 63) - 32*T*range - j).
+// right column's index j in the range (d = dmax + ((x - r) & 63) - 32*T*range - j); with the second-peak
+// output, a second plane per range: the best score among the range's right columns further than one from j.
 #pragma once
 
 #include "ncc_shared.h"
@@ -63,12 +64,16 @@ struct NccMfCfg {
 // EDGE = true: the other ranges, [0, seg0) and [seg1, seg1 + nranges - seg0): tiles outside the disparity range are
 // skipped, tiles on its edge masked per element.  Two kernels rather than two loops in one kernel: a kernel's
 // register allocation covers all its loops, and with both loops present the 96 accumulators spill.
-template <int R, bool EDGE>
+// WANT2: a second key plane per range: the best score among the range's right columns further than one column from
+// its winner (the second peak's candidate; the refinement merges the ranges).  Right columns fall into three
+// classes by index mod 3; the winner and its two neighbours sit in three different classes, so the best two keys
+// of every class are enough: a class whose best is one of the three contributes its second best.
+template <int R, bool EDGE, bool WANT2>
 __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     NccArgs a, int nblocks, int nranges, int seg0, int seg1,
     const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
     const uint32_t* __restrict__ gRpack, const float* __restrict__ gRsr, const float* __restrict__ gRir,
-    float* __restrict__ oKeys)
+    float* __restrict__ oKeys, float* __restrict__ oKeys2)
 {
     using Cfg = NccMfCfg<R>;
     constexpr int KS = Cfg::KS, T = NCC_MF_T, NB = NCC_MF_NB, CS = Cfg::CS, QR = Cfg::QR, QL = Cfg::QL;
@@ -295,6 +300,32 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         const uint32_t out = (sb & 0xFFFFFF80u) | (uint32_t)(up ? j1 : j0);
         const int x = X0 + lane;
         if (x < a.W - R) oKeys[((size_t)range * a.H + yout) * a.out_pitch + x] = __builtin_bit_cast(float, out);
+        return up ? j1 : j0;
+    };
+    // second plane: m1 / m2 = best / second-best key per class of the lane's share of right columns, [block][label];
+    // a register's label is its right column's index mod 3 in the lower half-wave, one less than it (mod 3) in the upper
+    auto emit2 = [&](float (&m1)[NB][3], float (&m2)[NB][3], int jstar, int yout) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(m1[0][q]), "+v"(m1[1][q]));   // [0]: the lower half-wave's, [1]: the upper's
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(m2[0][q]), "+v"(m2[1][q]));
+        }
+        float k2 = NCC_MF_LOW;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const float a1 = m1[0][q], a2 = m2[0][q], b1 = m1[1][(q + 2) % 3], b2 = m2[1][(q + 2) % 3];
+            const bool bw = b1 > a1;
+            const float hi = bw ? b1 : a1, lo = bw ? a1 : b1;
+            const uint32_t tg = __builtin_bit_cast(uint32_t, hi) & 63u;
+            const int jm = (int)(32u * (tg >> 4) + 8u * ((tg >> 2) & 3u) + (tg & 3u)) + (bw ? 4 : 0);
+            float nx = lo > a2 ? lo : a2;
+            nx = nx > b2 ? nx : b2;
+            const float cand = ((unsigned)(jm - jstar + 1) <= 2u) ? nx : hi;
+            k2 = cand > k2 ? cand : k2;
+        }
+        const uint32_t out = __builtin_bit_cast(uint32_t, k2) & 0xFFFFFF80u;
+        const int x = X0 + lane;
+        if (x < a.W - R) oKeys2[((size_t)range * a.H + yout) * a.out_pitch + x] = __builtin_bit_cast(float, out);
     };
 
     // ---- warm-up rows: the window fills, nothing is scored, no correction ----
@@ -335,6 +366,13 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
 #pragma unroll
         for (int c = 0; c < NB; c++) cprev[c] = ccur[c] ^ 0x80008000u;
         float best[NB] = { NCC_MF_LOW, NCC_MF_LOW };
+        float m1[NB][3], m2[NB][3];
+        if (WANT2) {
+#pragma unroll
+            for (int c = 0; c < NB; c++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) m1[c][q] = m2[c][q] = NCC_MF_LOW;
+        }
 #pragma unroll
         for (int t = 0; t < T; t++) {
             if (EDGE && !((ab >> (t * NB)) & ((1u << NB) - 1u))) continue;
@@ -372,6 +410,38 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float k0, k1, k2, k3;
+                    if constexpr (WANT2) {
+                        // the four registers' labels are L, L+1, L+2, L (mod 3): best two per class by v_med3 / v_max
+                        const int L = (2 * t + 2 * j) % 3;
+                        float &A1 = m1[c][L], &A2 = m2[c][L], &B1 = m1[c][(L + 1) % 3], &B2 = m2[c][(L + 1) % 3],
+                              &C1 = m1[c][(L + 2) % 3], &C2 = m2[c][(L + 2) % 3];
+                        asm("v_mul_f32 %6, %14, %15\n\t"
+                            "v_mul_f32 %7, %14, %16\n\t"
+                            "v_mul_f32 %8, %14, %17\n\t"
+                            "v_mul_f32 %9, %14, %18\n\t"
+                            "v_fmac_f32 %6, %10, %19\n\t"
+                            "v_fmac_f32 %7, %11, %20\n\t"
+                            "v_fmac_f32 %8, %12, %21\n\t"
+                            "v_fmac_f32 %9, %13, %22\n\t"
+                            "v_and_or_b32 %6, %6, %23, %24\n\t"
+                            "v_and_or_b32 %7, %7, %23, %25\n\t"
+                            "v_and_or_b32 %8, %8, %23, %26\n\t"
+                            "v_and_or_b32 %9, %9, %23, %27\n\t"
+                            "v_med3_f32 %1, %0, %1, %6\n\t"
+                            "v_med3_f32 %3, %2, %3, %7\n\t"
+                            "v_med3_f32 %5, %4, %5, %8\n\t"
+                            "v_max_f32 %0, %0, %6\n\t"
+                            "v_max_f32 %2, %2, %7\n\t"
+                            "v_max_f32 %4, %4, %8\n\t"
+                            "v_med3_f32 %1, %0, %1, %9\n\t"
+                            "v_max_f32 %0, %0, %9"
+                            : "+v"(A1), "+v"(A2), "+v"(B1), "+v"(B2), "+v"(C1), "+v"(C2), "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3)
+                            : "v"(acc[t][c][4 * j]), "v"(acc[t][c][4 * j + 1]), "v"(acc[t][c][4 * j + 2]), "v"(acc[t][c][4 * j + 3]),
+                              "v"(ng[c]), "v"(qv[j][0]), "v"(qv[j][1]), "v"(qv[j][2]), "v"(qv[j][3]),
+                              "v"(ir[4 * j]), "v"(ir[4 * j + 1]), "v"(ir[4 * j + 2]), "v"(ir[4 * j + 3]), "s"(kmask),
+                              "n"(16 * t + 4 * j), "n"(16 * t + 4 * j + 1), "n"(16 * t + 4 * j + 2), "n"(16 * t + 4 * j + 3));
+                        continue;
+                    }
                     asm("v_mul_f32 %1, %9, %10\n\t"
                         "v_mul_f32 %2, %9, %11\n\t"
                         "v_mul_f32 %3, %9, %12\n\t"
@@ -398,7 +468,17 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         // single-buffered LDS image: every read of this row was issued above and LDS executes a wavefront's
         // operations in order, so the next row may be written now
         publish(false, yout + 1);
-        emit(best[0], best[1], yout);
+        if constexpr (WANT2) {
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                const float m01 = m1[c][0] > m1[c][1] ? m1[c][0] : m1[c][1];
+                best[c] = m01 > m1[c][2] ? m01 : m1[c][2];
+            }
+            const int jstar = emit(best[0], best[1], yout);
+            emit2(m1, m2, jstar, yout);
+        } else {
+            emit(best[0], best[1], yout);
+        }
     }
     }
 }

@@ -61,6 +61,24 @@ def test_peak2_chunk_boundaries(ctx, dtype, window, dmin, dmax, shape, shift):
     assert st["valid"] > 0
 
 
+@pytest.mark.parametrize("window,dmin,dmax,shape,shift", [
+    (21, -100, 100, (60, 400), 4),       # dmax - shift = 96: in every 64th column the winner is right column 0 of the second range
+    (21, -100, 100, (60, 400), 5),       # ... and right column 95 of the first range in the next column over
+    (9, -256, 256, (40, 700), 64),       # 513 disparities, six ranges: winners on the boundary between ranges 2 and 3
+    (5, -40, 250, (40, 500), 59),        # boundary winners in edge ranges (masked tiles on both sides)
+    (15, 0, 94, (50, 300), 0),           # a single range, winner in its last right columns
+    (3, -2, 2, (30, 200), 1),            # five disparities
+])
+def test_peak2_range_boundaries_matrix_core(ctx, window, dmin, dmax, shape, shift):
+    """Second peak on the matrix-core kernels (windows up to 21): a wavefront's range of 96 right columns starts at
+    disparity dmax + ((x - r) & 63), so with a constant shift the winner walks through every position of a range as
+    x grows -- including the first and last one, where the excluded neighbour belongs to the next range's plane."""
+    left = synth.texture(shape[0], shape[1], 91 + window)
+    right = synth.shift_right_image(left, shift, fill_seed=92)
+    st = _run(ctx, left, right, window, dmin, dmax, peak2=True)
+    assert st["valid"] > 0
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_peak2_random(ctx, seed):
     window, h, w, dmin, dmax, dtype, shift = _random_case(3000 + seed)

@@ -1,7 +1,8 @@
 """Randomised parity stress of the dense NCC (8-bit, windows 3..21: the matrix-core kernels; wider windows and
 16-bit: the vector kernels) against the CPU oracle, beyond the cases the test-suite pins:
    python tools/stress_ncc.py [cases] [seed]
-Every case: random frame shape, window, search range, shift, optional row strip; prints a line per failure."""
+Every case: random frame shape, window, search range, shift, optional row strip or second-peak output; prints a
+line per failure."""
 import os, sys
 R0 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R0 + '/image-processing_amd', R0 + '/oracle', R0 + '/tests']
@@ -30,6 +31,7 @@ for k in range(cases):
         left[h // 4: h // 2, w // 5: w // 2] = int(rng.integers(0, 256))      # flat patch
     if rng.random() < 0.15:
         right = (rng.integers(0, 2, right.shape) * 255).astype(np.uint8)      # extreme contrast
+    want2 = False
     try:
         ctx.upload_pair(left, right)
         if rng.random() < 0.4 and h > window + 3:
@@ -49,11 +51,12 @@ for k in range(cases):
             sl = slice(row0, row0 + nrows)
             ora = {k2: (v[sl] if isinstance(v, np.ndarray) and v.shape[:1] == (h,) else v) for k2, v in ora.items()}
         else:
-            gpu = ctx.ncc_dense(window, dmin, dmax, want_idisp=True)
-            ora = oracle.ncc_dense(left, right, window, dmin, dmax, want_volume=True)
+            want2 = rng.random() < 0.4
+            gpu = ctx.ncc_dense(window, dmin, dmax, want_idisp=True, want_peak2=want2)
+            ora = oracle.ncc_dense(left, right, window, dmin, dmax, want_volume=True, want_peak2=want2)
             ora["flat"] = flat_mask(ora["volume"], ora["idisp"], dmin)
         try:
-            compare_ncc(gpu, ora, volume=ora["volume"], dmin=dmin)
+            compare_ncc(gpu, ora, volume=ora["volume"], dmin=dmin, check_peak2=want2)
         except AssertionError as e:
             # frames of a few hundred pixels miss the suite's 99.9 % agreement bar with two or three near-ties:
             # here every difference must be a near-tie in the oracle's volume and there must be few of them
