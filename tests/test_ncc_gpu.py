@@ -1,4 +1,6 @@
 """Dense-NCC parity: libmistereo (HIP, through the C ABI) against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,7 @@ import synth
 from ncc_util import compare_ncc, flat_mask
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(ctx, left, right, window, dmin, dmax, peak2=False):
@@ -395,3 +398,28 @@ def test_strips_in_any_order_build_only_their_rows(ctx, dtype):
     ys, xs = torch.nonzero(bad, as_tuple=True)
     assert not bad.any(), "%d pixels differ: rows %s, columns %d..%d" % (
         int(bad.sum()), sorted(set(ys.cpu().tolist()))[:12], int(xs.min()), int(xs.max()))
+
+
+def test_vector_kernels_behind_the_switch(tmp_path):
+    """MISTEREO_NCC_MFMA=0 sends windows up to 21 to the vector kernels (the A/B switch of the benchmarks): the
+    variable is read once per process, so the case runs in a child process; disparity, peak and second peak
+    against the oracle like every other case."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path[:0] = %r\n"
+        "import numpy as np, mistereo, oracle, synth\n"
+        "from ncc_util import compare_ncc, flat_mask\n"
+        "left = synth.texture(70, 500, 4242); right = synth.shift_right_image(left, 63, fill_seed=7)\n"
+        "ctx = mistereo.Context(0); ctx.upload_pair(left, right)\n"
+        "for win, dmin, dmax in ((21, -128, 128), (9, -100, 27)):\n"
+        "    gpu = ctx.ncc_dense(win, dmin, dmax, want_idisp=True, want_peak2=True)\n"
+        "    ora = oracle.ncc_dense(left, right, win, dmin, dmax, want_peak2=True, want_volume=True)\n"
+        "    ora['flat'] = flat_mask(ora['volume'], ora['idisp'], dmin)\n"
+        "    st = compare_ncc(gpu, ora, volume=ora['volume'], dmin=dmin, check_peak2=True)\n"
+        "    assert st['valid'] > 0\n"
+        "print('ok')\n"
+    ) % ([os.path.join(ROOT, "image-processing_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")],)
+    env = dict(os.environ, MISTEREO_NCC_MFMA="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
