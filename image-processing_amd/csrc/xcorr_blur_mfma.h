@@ -1,0 +1,213 @@
+// The 151-tap Gaussian of the difference-of-Gaussian peak pick (image3.cpp:481-483) on the matrix cores, gfx950.
+//
+// A 1-D filter along a line is a product with a banded Toeplitz matrix: out[n] = sum_j g[j] * pad[n + j], i.e.
+// Out(32 lines x 32 outputs) = Pad(32 lines x 192 samples) * G(192 x 32), G[k][n] = g[k - n] inside the band.
+// v_mfma_f32_32x32x16_f16 takes f16 operands, and the surfaces need more than f16's 11 bits, so every operand is
+// split in two halves (value = hi + lo, lo = the f16 nearest to the remainder: 22 bits together) and a product
+// is three matrix products, hi*hi + hi*lo + lo*hi, accumulated in f32 (the lo*lo term is below 2^-22 of the
+// result).  The taps are scaled by 128 for the split so that their low halves stay normal f16 numbers.
+// The sums are not accumulated in the tap order of the vector kernels (which follow the filter loops of the
+// reference's library); the results differ from theirs by a few 1e-7 of the surface's range.
+//
+//   rows pass    one workgroup = 32 rows of a tile: normalise (image3.cpp:414-416), the padded rows
+//                (BORDER_REFLECT_101) as f16 halves in LDS, 32 x 32 output tiles per wavefront
+//   columns pass one workgroup = 32 columns of a tile over all rows: the row-filtered columns transposed into LDS
+//                (a column is a "line" there), the same product, then DoG = surface - blur and the first maximum
+// Both need tile sides that are multiples of 32 (no odd-size rule applies) and at most 1024 (LDS).
+#pragma once
+
+typedef _Float16 xb_half8 __attribute__((ext_vector_type(8)));
+typedef float xb_f32x16 __attribute__((ext_vector_type(16)));
+
+#define XB_KSTEPS 12            // 16-sample steps: 32 outputs + 150 more samples = 182 <= 192
+#define XB_TAPSCALE 128.0f
+
+// line stride in f16 elements: room for L + 160 samples (75 + L + 75 reflected ones, zero padded to the end of
+// the last 16-sample step), 16-byte aligned lines whose starts fall on different bank groups
+static inline int xb_line_stride(int L) { int s = L + 160; while (s % 16 != 8) s++; return s; }
+static inline size_t xb_lds_bytes(int L) { return (size_t)2 * 32 * xb_line_stride(L) * sizeof(_Float16); }
+static inline bool xb_fits(int w, int h)
+{
+    return w % 32 == 0 && h % 32 == 0 && w >= 32 && h >= 32 && xb_lds_bytes(w) <= 160 * 1024 && xb_lds_bytes(h) <= 160 * 1024;
+}
+
+// The Toeplitz operand: lane l holds, for output n = l & 31, the taps of samples 16 s + 8 (l >> 5) + e (e = 0..7) of step s.
+// Built once per context into a table of 2 * XB_KSTEPS * 64 vectors ([step][hi, lo][lane]), 24 coalesced loads per lane
+// in the filter kernels.
+__global__ void xb_build_taps(const float* __restrict__ gauss, xb_half8* __restrict__ table)
+{
+    const int lane = threadIdx.x, n = lane & 31, kg = lane >> 5;
+    for (int s = 0; s < XB_KSTEPS; s++) {
+        xb_half8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int gi = 16 * s + 8 * kg + e - n;
+            const float v = (gi >= 0 && gi < XC_GAUSS_K) ? gauss[gi] * XB_TAPSCALE : 0.f;
+            const _Float16 a = (_Float16)v;
+            h[e] = a;
+            l[e] = (_Float16)(v - (float)a);
+        }
+        table[(2 * s) * 64 + lane] = h;
+        table[(2 * s + 1) * 64 + lane] = l;
+    }
+}
+__device__ __forceinline__ void xb_taps(const xb_half8* __restrict__ table, int lane, xb_half8 (&bh)[XB_KSTEPS], xb_half8 (&bl)[XB_KSTEPS])
+{
+#pragma unroll
+    for (int s = 0; s < XB_KSTEPS; s++) {
+        bh[s] = table[(2 * s) * 64 + lane];
+        bl[s] = table[(2 * s + 1) * 64 + lane];
+    }
+}
+
+// 32 lines x 32 outputs starting at sample `first` of every line (lines of this lane: lane & 31)
+__device__ __forceinline__ xb_f32x16 xb_block(const _Float16* hi, const _Float16* lo, int SW, int first, int lane,
+                                              const xb_half8 (&bh)[XB_KSTEPS], const xb_half8 (&bl)[XB_KSTEPS])
+{
+    xb_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    const int base = (lane & 31) * SW + first + 8 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < XB_KSTEPS; s++) {
+        const xb_half8 ah = *(const xb_half8*)(hi + base + 16 * s);
+        const xb_half8 al = *(const xb_half8*)(lo + base + 16 * s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// stage 4 on the matrix cores: grid (h / 32, tiles), 512 threads.  Same outputs as xc_norm_rowblur: the normalised
+// surface back into `surf`, the row-filtered one into `tmp`.
+__global__ __launch_bounds__(512) void xc_norm_rowblur_mf(int w, int h, int SW, const unsigned* __restrict__ minmax,
+                                                          const xb_half8* __restrict__ taps,
+                                                          float* __restrict__ surf, float* __restrict__ tmp, int pre)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char xb_smem[];
+    _Float16* hi = (_Float16*)xb_smem;
+    _Float16* lo = hi + 32 * SW;
+    const int t = blockIdx.y, y0 = 32 * blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float mn = __uint_as_float(minmax[2 * t]), mx = __uint_as_float(minmax[2 * t + 1]);
+    const float range = mx - mn;
+    xb_half8 bh[XB_KSTEPS], bl[XB_KSTEPS];
+    xb_taps(taps, lane, bh, bl);
+    float* sblk = surf + ((size_t)t * h + y0) * w;  // the block's 32 rows are contiguous
+    // 16 bytes per thread and load, eight loads in flight before the first store (the stores go to the array
+    // the loads read, so nothing is reordered across them by the compiler)
+    const int total = 32 * w;
+    for (int f0 = 4 * tid; f0 < total; f0 += 8 * 2048) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = *(const float4*)(sblk + min(f0 + 2048 * k, total - 4));
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int f = f0 + 2048 * k;
+            if (f >= total) continue;
+            float o[4] = { v[k].x, v[k].y, v[k].z, v[k].w };
+            if (!pre) {                                  // pre: the surface already holds the product of the normalised band surfaces
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = (float)(((double)o[e] - (double)mn) / (double)range);
+                *(float4*)(sblk + f) = make_float4(o[0], o[1], o[2], o[3]);   // the normalised surface, kept for stage 5
+            }
+            const int r = f / w, x = f - r * w;         // w is a multiple of 4: the four samples share a row
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const _Float16 a = (_Float16)o[e];
+                hi[r * SW + XC_GAUSS_R + x + e] = a;
+                lo[r * SW + XC_GAUSS_R + x + e] = (_Float16)(o[e] - (float)a);
+            }
+        }
+    }
+    __syncthreads();
+    // the 75 reflected samples on either side, zeros up to the end of the last step
+    for (int idx = tid; idx < 32 * 160; idx += 512) {
+        const int r = idx / 160, j = idx % 160;
+        const int i = j < XC_GAUSS_R ? j : w + j;   // j = 75..159 -> samples w + 75 .. w + 159
+        _Float16 vh = (_Float16)0.f, vl = (_Float16)0.f;
+        if (i < w + 2 * XC_GAUSS_R) {
+            const int sx = reflect101(i - XC_GAUSS_R, w);
+            vh = hi[r * SW + XC_GAUSS_R + sx];
+            vl = lo[r * SW + XC_GAUSS_R + sx];
+        }
+        hi[r * SW + i] = vh;
+        lo[r * SW + i] = vl;
+    }
+    __syncthreads();
+    float* tblk = tmp + ((size_t)t * h + y0) * w;
+    const int n = lane & 31, kg = lane >> 5;
+    for (int b = wv; b < w / 32; b += 8) {
+        const xb_f32x16 acc = xb_block(hi, lo, SW, 32 * b, lane, bh, bl);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int row = 8 * (i >> 2) + 4 * kg + (i & 3);
+            tblk[(size_t)row * w + 32 * b + n] = acc[i] * (1.0f / XB_TAPSCALE);
+        }
+    }
+}
+
+// stage 5 on the matrix cores: grid (w / 32, tiles), 512 threads.  Same outputs as xc_colblur_argmax.
+__global__ __launch_bounds__(512) void xc_colblur_argmax_mf(int w, int h, int SW, const xb_half8* __restrict__ taps,
+                                                            const float* __restrict__ surf, const float* __restrict__ tmp,
+                                                            float* __restrict__ dog_out, unsigned long long* __restrict__ keys)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char xb_smem[];
+    _Float16* hi = (_Float16*)xb_smem;
+    _Float16* lo = hi + 32 * SW;
+    const int t = blockIdx.y, x0 = 32 * blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    xb_half8 bh[XB_KSTEPS], bl[XB_KSTEPS];
+    xb_taps(taps, lane, bh, bl);
+    const float* tt = tmp + (size_t)t * h * w;
+    // the columns as lines: sample i of line c is row reflect(i - 75) of column x0 + c; 16 rows per pass, sixteen
+    // passes' loads in flight before the first store
+    const int c = tid & 31, ri = tid >> 5;
+    const int npass = (h + 160) / 16;               // h is a multiple of 32
+    for (int q0 = 0; q0 < npass; q0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = min(16 * (q0 + k) + ri, h + 2 * XC_GAUSS_R - 1);
+            v[k] = tt[(size_t)reflect101(i - XC_GAUSS_R, h) * w + x0 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = 16 * (q0 + k) + ri;
+            if (q0 + k < npass) {
+                const float o = i < h + 2 * XC_GAUSS_R ? v[k] : 0.f;
+                const _Float16 a = (_Float16)o;
+                hi[c * SW + i] = a;
+                lo[c * SW + i] = (_Float16)(o - (float)a);
+            }
+        }
+    }
+    __syncthreads();
+    const int n = lane & 31, kg = lane >> 5;
+    unsigned long long best = 0;
+    for (int b = wv; b < h / 32; b += 8) {
+        const xb_f32x16 acc = xb_block(hi, lo, SW, 32 * b, lane, bh, bl);
+        const int y = 32 * b + n;
+        const size_t orow = (size_t)t * h * w + (size_t)y * w;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; i4++) {
+            const int x = x0 + 8 * i4 + 4 * kg;
+            const float4 sf = *(const float4*)(surf + orow + x);
+            const float s4[4] = { sf.x, sf.y, sf.z, sf.w };
+            float d4[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                d4[e] = __fsub_rn(s4[e], acc[4 * i4 + e] * (1.0f / XB_TAPSCALE));
+                if (d4[e] > -1.0f) {
+                    const unsigned long long k = argmax_key(d4[e], (unsigned)(y * w + x + e));
+                    best = k > best ? k : best;
+                }
+            }
+            if (dog_out) *(float4*)(dog_out + orow + x) = make_float4(d4[0], d4[1], d4[2], d4[3]);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o);
+        best = other > best ? other : best;
+    }
+    tile_commit_key(keys, t, best);
+}

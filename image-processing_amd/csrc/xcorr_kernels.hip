@@ -30,6 +30,7 @@ struct XcorrWs {
     std::map<int, float2*> twiddle;     // per FFT length n: n/2 values exp(-2 pi i k / n)
     std::map<int, float2*> chirp;       // per non-power-of-two length n: n chirp values, then the M filter values
     float* gauss = nullptr;             // 151 taps
+    void* taps_mf = nullptr;            // the taps as matrix-core operands (xcorr_blur_mfma.h), built on first use
     void* buf = nullptr; size_t buf_bytes = 0;      // spectra / surfaces of one batch of tiles
     void* meta = nullptr; size_t meta_bytes = 0;    // per-tile min/max, argmax keys, rects
     const float* last_surface = nullptr;            // normalised surfaces of the last batch (inspection)
@@ -43,6 +44,7 @@ void mis_xcorr_release(mis_ctx* ctx)
     for (auto& kv : w->twiddle) (void)hipFree(kv.second);
     for (auto& kv : w->chirp) (void)hipFree(kv.second);
     if (w->gauss) (void)hipFree(w->gauss);
+    if (w->taps_mf) (void)hipFree(w->taps_mf);
     if (w->buf) (void)hipFree(w->buf);
     if (w->meta) (void)hipFree(w->meta);
     delete w;
@@ -1128,6 +1130,48 @@ static int make_plan(mis_ctx* ctx, int w, int h, XcPlan* p)
 
 // correlates tiles [tile0, tile0+nt) of the rect lists (device pointers); results to d_out[tile0..]
 // peak_stages false: stop after stage 3 (|c| surface and its extrema)
+#include "xcorr_blur_mfma.h"
+
+// stages 4 and 5 of a batch: the Gaussian on the matrix cores where the tile shape allows it (MISTEREO_XC_MFMA=0
+// keeps the vector kernels, for comparisons), else the vector kernels
+static int launch_blur_stages(mis_ctx* ctx, int w, int h, int nt, const unsigned* minmax, float* fsurf, float* tmp, bool pre,
+                              float* dog_dbg, unsigned long long* keys)
+{
+    XcorrWs* ws = ctx->xc;
+    hipStream_t s = ctx->stream;
+    static const int mf_env = [] { const char* e = getenv("MISTEREO_XC_MFMA"); return e ? atoi(e) : 1; }();
+    if (mf_env != 0 && xb_fits(w, h)) {
+        if (!ws->taps_mf) {
+            MIS_HIP(ctx, hipMalloc(&ws->taps_mf, (size_t)2 * XB_KSTEPS * 64 * sizeof(xb_half8)));
+            hipLaunchKernelGGL(xb_build_taps, dim3(1), dim3(64), 0, s, ws->gauss, (xb_half8*)ws->taps_mf);
+        }
+        const xb_half8* taps = (const xb_half8*)ws->taps_mf;
+        const size_t sha = xb_lds_bytes(w), shb = xb_lds_bytes(h);
+        if (sha > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sha));
+        if (shb > 64 * 1024)
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_colblur_argmax_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+        hipLaunchKernelGGL(xc_norm_rowblur_mf, dim3(h / 32, nt), dim3(512), sha, s, w, h, xb_line_stride(w), minmax, taps, fsurf, tmp, pre ? 1 : 0);
+        hipLaunchKernelGGL(xc_colblur_argmax_mf, dim3(w / 32, nt), dim3(512), shb, s, w, h, xb_line_stride(h), taps, fsurf, tmp, dog_dbg, keys);
+        return MIS_OK;
+    }
+    {
+        const size_t sh = (size_t)(152 + 2 * w + 168) * sizeof(float);
+        if (w >= 1024 || (w & 3)) {
+            if (sh > 64 * 1024)
+                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            hipLaunchKernelGGL(xc_norm_rowblur<256>, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, pre);
+        } else if (w >= 512) {
+            hipLaunchKernelGGL(xc_norm_rowblur<128>, dim3(h, nt), dim3(128), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, pre);
+        } else {
+            hipLaunchKernelGGL(xc_norm_rowblur<64>, dim3(h, nt), dim3(64), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, pre);
+        }
+    }
+    hipLaunchKernelGGL(xc_colblur_argmax, dim3((w + 63) / 64, (h + XC_RB5 - 1) / XC_RB5, nt), dim3(256), 0, s,
+                       w, h, ws->gauss, fsurf, tmp, dog_dbg, keys);
+    return MIS_OK;
+}
+
 static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const mis_rect* d_r2,
                      int tile0, int nt, mis_offset* d_out, float* dog_dbg, bool peak_stages = true)
 {
@@ -1190,20 +1234,8 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
             hipLaunchKernelGGL(xc_band_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, N, minmax, surf, prod, band == 0);
     }
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
-    {
-        const size_t sh = (size_t)(152 + 2 * w + 168) * sizeof(float);
-        if (w >= 1024 || (w & 3)) {
-            if (sh > 64 * 1024)
-                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            hipLaunchKernelGGL(xc_norm_rowblur<256>, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
-        } else if (w >= 512) {
-            hipLaunchKernelGGL(xc_norm_rowblur<128>, dim3(h, nt), dim3(128), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
-        } else {
-            hipLaunchKernelGGL(xc_norm_rowblur<64>, dim3(h, nt), dim3(64), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
-        }
-    }
-    hipLaunchKernelGGL(xc_colblur_argmax, dim3((w + 63) / 64, (h + XC_RB5 - 1) / XC_RB5, nt), dim3(256), 0, s,
-                       w, h, ws->gauss, fsurf, tmp, dog_dbg, keys);
+    rc = launch_blur_stages(ctx, w, h, nt, minmax, fsurf, tmp, nbands > 1, dog_dbg, keys);
+    if (rc) return rc;
     hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, fsurf, d_out + tile0);
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
@@ -1253,20 +1285,8 @@ static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1
             hipLaunchKernelGGL(xc_band_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, N, minmax, surf, prod, band == 0);
     }
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
-    {
-        const size_t sh = (size_t)(152 + 2 * w + 168) * sizeof(float);
-        if (w >= 1024 || (w & 3)) {
-            if (sh > 64 * 1024)
-                MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_norm_rowblur<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            hipLaunchKernelGGL(xc_norm_rowblur<256>, dim3(h, nt), dim3(256), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
-        } else if (w >= 512) {
-            hipLaunchKernelGGL(xc_norm_rowblur<128>, dim3(h, nt), dim3(128), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
-        } else {
-            hipLaunchKernelGGL(xc_norm_rowblur<64>, dim3(h, nt), dim3(64), sh, s, w, h, minmax, ws->gauss, fsurf, tmp, nbands > 1);
-        }
-    }
-    hipLaunchKernelGGL(xc_colblur_argmax, dim3((w + 63) / 64, (h + XC_RB5 - 1) / XC_RB5, nt), dim3(256), 0, s,
-                       w, h, ws->gauss, fsurf, tmp, dog_dbg, keys);
+    rc = launch_blur_stages(ctx, w, h, nt, minmax, fsurf, tmp, nbands > 1, dog_dbg, keys);
+    if (rc) return rc;
     hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, fsurf, d_out + tile0);
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;

@@ -1,10 +1,16 @@
 """Turns the rocprofv3 outputs merged back under gpurun_out/<tag>_{stats,fetch,write,sq} (tools/profile_round.sh)
 into the committed summaries under profiles/<round>_*.  Usage: python tools/summarise_round.py <tag> <round>"""
-import collections, csv, json, os, shutil, sys
+import collections, csv, json, os, re, shutil, sys
 tag, rnd = sys.argv[1], sys.argv[2]
 G = lambda n: os.path.join("gpurun_out", "%s_%s" % (tag, n))
 OURS = ("ncc_", "ncc16_", "xc_", "xg_", "tri_")
-short = lambda name: name.split("(")[0].replace("void ", "")
+def short(name):
+    """Kernel name without its argument list; names the profiler leaves mangled (_Z<len><name>...) are cut out by length."""
+    m = re.match(r"_Z(\d+)", name)
+    if m:
+        n = int(m.group(1))
+        return name[m.end():m.end() + n]
+    return name.split("(")[0].replace("void ", "")
 shutil.copy(os.path.join(G("stats"), "s_kernel_stats.csv"), "profiles/%s_kernel_stats.csv" % rnd)
 if os.path.exists(G("ubench.txt")):
     shutil.copy(G("ubench.txt"), "profiles/%s_ubench_valu_rates.txt" % rnd)
