@@ -52,6 +52,8 @@ def parse(argv=None):
                     help="rows of the frame the CPU oracle is timed on (0: skip the CPU baseline)")
     ap.add_argument("--extras", choices=["on", "off"], default="on",
                     help="at N=1: also measure the FFT tile correlation and the 16-bit dense NCC")
+    ap.add_argument("--second-peak", choices=["on", "off"], default="on",
+                    help="at N=1 with extras: also time the step with the second-peak output (off for counter passes that sum per step)")
     return ap.parse_args(argv)
 
 
@@ -614,7 +616,7 @@ def main():
                 "parity": rep,
             }
             del ora, gd, gp, gi, idisp
-        if world == 1 and args.extras == "on":
+        if world == 1 and args.extras == "on" and args.second_peak == "on":
             # the same step with the second-peak output (best score further than one disparity from the winner)
             pk2 = torch.empty((H, W), dtype=torch.float32, device=dev)
             with torch.cuda.stream(stream):
@@ -631,6 +633,7 @@ def main():
                                      "gpx_disp_per_s": round(float(H) * W * nd / ms2 / 1e6, 1),
                                      "note": "same pair and search with the peak2 raster requested; parity of peak2 is covered by the GPU tests"}
             del pk2
+        if world == 1 and args.extras == "on":
             result["path_f"] = bench_path_f(ctx, stream, dev, left_h, cpu=args.cpu_rows > 0)
             result["ncc16"] = bench_ncc16(ctx, stream, dev, cpu=args.cpu_rows > 0)
         print(json.dumps(result), flush=True)

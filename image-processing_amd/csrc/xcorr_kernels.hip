@@ -7,8 +7,10 @@
 //   2 forward column FFTs, A*conj(B) from the joint spectrum, inverse column FFT,     xc_cols
 //     fused
 //   3 inverse row FFT, |c|, tile min / max                                           xc_rows_inv_abs
-//   4 min-max normalisation to [0,1] and the row pass of the 151-tap Gaussian         xc_norm_rowblur
-//   5 column pass, difference of Gaussians, first maximum                             xc_colblur_argmax
+//   4 min-max normalisation to [0,1] and the row pass of the 151-tap Gaussian         xc_norm_rowblur[_mf]
+//   5 column pass, difference of Gaussians, first maximum                             xc_colblur_argmax[_mf]
+//     (_mf: the filter as a banded Toeplitz product on the matrix cores, xcorr_blur_mfma.h, for tile sides that
+//     are multiples of 32 up to 1024; the vector kernels follow the tap order of the reference's filter loops)
 //   6 wrap the peak position to a signed offset                                       xc_finish
 // Every 1-D transform lives in LDS.  Forward transforms are decimation-in-frequency (natural
 // order in, bit-reversed out), inverse ones decimation-in-time (bit-reversed in, natural out),

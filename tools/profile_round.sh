@@ -9,9 +9,10 @@ tag=$1
 export TMPDIR=/tmp
 O=gpurun_out
 B="python3 bench.py --cpu-rows 0"
+P="$B --second-peak off"      # counter passes: exactly one plain step, so per-step sums are sums over the run
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/${tag}_stats -o s --output-format csv -- $B --steps 5 --warmup 1 > $O/${tag}_stats.log 2>&1 &&
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/${tag}_fetch -o p --output-format csv -- $B --steps 1 --warmup 0 > $O/${tag}_fetch.log 2>&1 &&
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/${tag}_write -o p --output-format csv -- $B --steps 1 --warmup 0 > $O/${tag}_write.log 2>&1 &&
-timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY -d $O/${tag}_sq -o p --output-format csv -- $B --steps 1 --warmup 1 > $O/${tag}_sq.log 2>&1 &&
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/${tag}_fetch -o p --output-format csv -- $P --steps 1 --warmup 0 > $O/${tag}_fetch.log 2>&1 &&
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/${tag}_write -o p --output-format csv -- $P --steps 1 --warmup 0 > $O/${tag}_write.log 2>&1 &&
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY -d $O/${tag}_sq -o p --output-format csv -- $P --steps 1 --warmup 1 > $O/${tag}_sq.log 2>&1 &&
 (timeout -k 5 120 ./tools/ubench/valu_rates 8 > $O/${tag}_ubench.txt 2>&1; timeout -k 5 120 ./tools/ubench/valu_rates64 8 >> $O/${tag}_ubench.txt 2>&1; true) &&
 echo done

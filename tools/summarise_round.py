@@ -23,7 +23,7 @@ for d, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         acc[k] += float(row["Counter_Value"]); cnt[k] += 1
     for k in acc: res.setdefault(k, {})[c] = acc[k] / cnt[k]; res[k]["launches_" + c] = cnt[k]
 with open("profiles/%s_pmc_hbm_traffic.csv" % rnd, "w") as f:
-    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --cpu-rows 0 --steps 1 --warmup 0\n")
+    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --cpu-rows 0 --second-peak off --steps 1 --warmup 0\n")
     f.write("# (8192x8192 u8 W21 +-256 step, triangulation, 256 x 512x512 FFT tile batches, 16384x1024 u16 W31 +-512 band)\n")
     f.write("# average KiB per launch as reported, launches in the run; on gfx950 FETCH_SIZE under-reports wide (16 B/lane) streaming reads by 2x,\n")
     f.write("# other access widths are uncalibrated: the values are raw\n")
@@ -40,7 +40,7 @@ def busy(k):
     den = g("SQ_BUSY_CYCLES") / 32 * 1024 / 4
     return (g("SQ_ACTIVE_INST_VALU") / den, g("SQ_ACTIVE_INST_LDS") / den) if den > 0 else (0.0, 0.0)
 with open("profiles/%s_pmc_sq.csv" % rnd, "w") as f:
-    f.write("# rocprofv3 --pmc " + " ".join(names) + " (one pass), bench.py --cpu-rows 0 --steps 1 --warmup 1\n")
+    f.write("# rocprofv3 --pmc " + " ".join(names) + " (one pass), bench.py --cpu-rows 0 --second-peak off --steps 1 --warmup 1\n")
     f.write("# per-launch averages summed over all shader engines; cycle counters are in units of 4 clocks;\n")
     f.write("# valu_busy = SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES / 32 * 1024 SIMDs / 4), lds_active likewise\n")
     f.write("kernel," + ",".join(names) + ",valu_busy,lds_active\n")
