@@ -15,6 +15,11 @@
  *     stream (mis_set_stream); the others take host pointers and return when results are in
  *     host memory
  *   - there is no CPU fallback: without a usable HIP device mis_create fails
+ *
+ * Environment (read once per process; for comparisons, the results stay within the same bars)
+ *   MISTEREO_NCC_MFMA=0   dense 8-bit NCC with windows up to 21 x 21 on the vector kernels instead of the matrix cores
+ *   MISTEREO_XC_MFMA=0    the Gaussian passes of the tile correlation on the vector kernels (tap order of the
+ *                         reference's filter loops) instead of the matrix cores
  */
 #ifndef MI_STEREO_H
 #define MI_STEREO_H
