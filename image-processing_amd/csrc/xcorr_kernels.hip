@@ -33,6 +33,8 @@ struct XcorrWs {
     std::map<int, float2*> chirp;       // per non-power-of-two length n: n chirp values, then the M filter values
     float* gauss = nullptr;             // 151 taps
     void* taps_mf = nullptr;            // the taps as matrix-core operands (xcorr_blur_mfma.h), built on first use
+    hipStream_t side = nullptr;         // second stream: the two halves of a batch run side by side
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* buf = nullptr; size_t buf_bytes = 0;      // spectra / surfaces of one batch of tiles
     void* meta = nullptr; size_t meta_bytes = 0;    // per-tile min/max, argmax keys, rects
     const float* last_surface = nullptr;            // normalised surfaces of the last batch (inspection)
@@ -47,6 +49,11 @@ void mis_xcorr_release(mis_ctx* ctx)
     for (auto& kv : w->chirp) (void)hipFree(kv.second);
     if (w->gauss) (void)hipFree(w->gauss);
     if (w->taps_mf) (void)hipFree(w->taps_mf);
+    if (w->side) {
+        (void)hipStreamSynchronize(w->side);
+        (void)hipEventDestroy(w->ev_fork); (void)hipEventDestroy(w->ev_join);
+        (void)hipStreamDestroy(w->side);
+    }
     if (w->buf) (void)hipFree(w->buf);
     if (w->meta) (void)hipFree(w->meta);
     delete w;
@@ -1259,17 +1266,26 @@ static int make_plan(mis_ctx* ctx, int w, int h, XcPlan* p)
 
 // stages 4 and 5 of a batch: the Gaussian on the matrix cores where the tile shape allows it (MISTEREO_XC_MFMA=0
 // keeps the vector kernels, for comparisons), else the vector kernels
-static int launch_blur_stages(mis_ctx* ctx, int w, int h, int nt, const unsigned* minmax, float* fsurf, float* tmp, bool pre,
+static bool blur_on_matrix_cores(int w, int h)
+{
+    static const int mf_env = [] { const char* e = getenv("MISTEREO_XC_MFMA"); return e ? atoi(e) : 1; }();
+    return mf_env != 0 && xb_fits(w, h);
+}
+// the matrix-core operand table, built on the context's stream before any stage that reads it is enqueued
+static int ensure_taps(mis_ctx* ctx, int w, int h)
+{
+    XcorrWs* ws = ctx->xc;
+    if (!blur_on_matrix_cores(w, h) || ws->taps_mf) return MIS_OK;
+    MIS_HIP(ctx, hipMalloc(&ws->taps_mf, (size_t)2 * XB_KSTEPS * 64 * sizeof(xb_half8)));
+    hipLaunchKernelGGL(xb_build_taps, dim3(1), dim3(64), 0, ctx->stream, ws->gauss, (xb_half8*)ws->taps_mf);
+    MIS_HIP(ctx, hipGetLastError());
+    return MIS_OK;
+}
+static int launch_blur_stages(mis_ctx* ctx, hipStream_t s, int w, int h, int nt, const unsigned* minmax, float* fsurf, float* tmp, bool pre,
                               float* dog_dbg, unsigned long long* keys)
 {
     XcorrWs* ws = ctx->xc;
-    hipStream_t s = ctx->stream;
-    static const int mf_env = [] { const char* e = getenv("MISTEREO_XC_MFMA"); return e ? atoi(e) : 1; }();
-    if (mf_env != 0 && xb_fits(w, h)) {
-        if (!ws->taps_mf) {
-            MIS_HIP(ctx, hipMalloc(&ws->taps_mf, (size_t)2 * XB_KSTEPS * 64 * sizeof(xb_half8)));
-            hipLaunchKernelGGL(xb_build_taps, dim3(1), dim3(64), 0, s, ws->gauss, (xb_half8*)ws->taps_mf);
-        }
+    if (blur_on_matrix_cores(w, h)) {
         const xb_half8* taps = (const xb_half8*)ws->taps_mf;
         const size_t sha = xb_lds_bytes(w), shb = xb_lds_bytes(h);
         if (sha > 64 * 1024)
@@ -1315,55 +1331,82 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
     float* fsurf = nbands > 1 ? prod : surf;                           // what stages 4-6 work on
     unsigned* minmax = (unsigned*)ws->meta;
     unsigned long long* keys = (unsigned long long*)((char*)ws->meta + (((size_t)nt * 8 + 255) & ~(size_t)255));
-    hipStream_t s = ctx->stream;
     const float scale = (float)(1.0 / sqrt((double)N));
-    size_t sh_rows = 0; bool pad_rows = false;      // LDS bytes and layout of the two row kernels
     ws->last_surface = fsurf;
     ws->last_abs = surf;
+    rc = ensure_taps(ctx, w, h); if (rc) return rc;
 
-    for (int band = 0; band < nbands; band++) {
-        XcImage im;
-        im.img[0] = band ? ctx->band_img[0][band - 1] : ctx->img[0];
-        im.img[1] = band ? ctx->band_img[1][band - 1] : ctx->img[1];
-        im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
-        {
-            // padded LDS layout whenever it fits (it does for every tile size but the largest)
-            const size_t nx = (size_t)p.RBw * w, nxp = ((nx + nx / 8 + 1) & ~(size_t)1);
-            const bool pad = (nx % 8 == 0) && (nxp + w / 2) * sizeof(float2) <= 160 * 1024;
-            sh_rows = ((pad ? nxp : nx) + w / 2) * sizeof(float2);
-            pad_rows = pad;
-            auto kf = pad ? xc_rows_fwd<true> : xc_rows_fwd<false>;
-            auto ki = pad ? xc_rows_inv_abs<true> : xc_rows_inv_abs<false>;
-            if (sh_rows > 64 * 1024) {
-                MIS_HIP(ctx, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_rows));
-                MIS_HIP(ctx, hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_rows));
+    // the stages for tiles [toff, toff + ntk) of the batch on stream s (the arrays keep the layout of the whole batch)
+    auto part = [&](int toff, int ntk, hipStream_t s) -> int {
+        float2* spec_p = spec + (size_t)toff * N;
+        float* surf_p = surf + (size_t)toff * N;
+        float* tmp_p = tmp + (size_t)toff * N;
+        float* prod_p = prod + (size_t)toff * N;
+        float* fsurf_p = nbands > 1 ? prod_p : surf_p;
+        unsigned* minmax_p = minmax + 2 * toff;
+        unsigned long long* keys_p = keys + toff;
+        size_t sh_rows = 0; bool pad_rows = false;      // LDS bytes and layout of the two row kernels
+        for (int band = 0; band < nbands; band++) {
+            XcImage im;
+            im.img[0] = band ? ctx->band_img[0][band - 1] : ctx->img[0];
+            im.img[1] = band ? ctx->band_img[1][band - 1] : ctx->img[1];
+            im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
+            {
+                // padded LDS layout whenever it fits (it does for every tile size but the largest)
+                const size_t nx = (size_t)p.RBw * w, nxp = ((nx + nx / 8 + 1) & ~(size_t)1);
+                const bool pad = (nx % 8 == 0) && (nxp + w / 2) * sizeof(float2) <= 160 * 1024;
+                sh_rows = ((pad ? nxp : nx) + w / 2) * sizeof(float2);
+                pad_rows = pad;
+                auto kf = pad ? xc_rows_fwd<true> : xc_rows_fwd<false>;
+                auto ki = pad ? xc_rows_inv_abs<true> : xc_rows_inv_abs<false>;
+                if (sh_rows > 64 * 1024) {
+                    MIS_HIP(ctx, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_rows));
+                    MIS_HIP(ctx, hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_rows));
+                }
+                hipLaunchKernelGGL(kf, dim3(h / p.RBw, ntk), dim3(256), sh_rows, s, im, d_r1, d_r2, tile0 + toff,
+                                   w, h, p.logw, p.RBw, tww, spec_p, minmax_p, band == 0 ? keys_p : (unsigned long long*)nullptr);
             }
-            hipLaunchKernelGGL(kf, dim3(h / p.RBw, nt), dim3(256), sh_rows, s, im, d_r1, d_r2, tile0,
-                               w, h, p.logw, p.RBw, tww, spec, minmax, band == 0 ? keys : (unsigned long long*)nullptr);
+            {
+                const size_t nx = (size_t)2 * p.CB * h, nxp = ((nx + nx / 8 + 1) & ~(size_t)1);
+                const bool pad = (nx % 8 == 0) && (nxp + h / 2) * sizeof(float2) <= 160 * 1024;
+                const size_t sh = ((pad ? nxp : nx) + h / 2) * sizeof(float2);
+                auto kc = pad ? xc_cols<true> : xc_cols<false>;
+                if (sh > 64 * 1024)
+                    MIS_HIP(ctx, hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                hipLaunchKernelGGL(kc, dim3(w / (2 * p.CB), ntk), dim3(512), sh, s, w, h, p.logw, p.logh, p.CB, scale * scale, twh, spec_p);
+            }
+            {
+                auto ki = pad_rows ? xc_rows_inv_abs<true> : xc_rows_inv_abs<false>;
+                hipLaunchKernelGGL(ki, dim3(h / p.RBw, ntk), dim3(256), sh_rows, s, w, h, p.logw, p.RBw, scale,
+                                   tww, spec_p, surf_p, minmax_p);
+            }
+            if (nbands > 1)
+                hipLaunchKernelGGL(xc_band_product, dim3((unsigned)((N + 255) / 256), ntk), dim3(256), 0, s, N, minmax_p, surf_p, prod_p, band == 0);
         }
-        {
-            const size_t nx = (size_t)2 * p.CB * h, nxp = ((nx + nx / 8 + 1) & ~(size_t)1);
-            const bool pad = (nx % 8 == 0) && (nxp + h / 2) * sizeof(float2) <= 160 * 1024;
-            const size_t sh = ((pad ? nxp : nx) + h / 2) * sizeof(float2);
-            auto kc = pad ? xc_cols<true> : xc_cols<false>;
-            if (sh > 64 * 1024)
-                MIS_HIP(ctx, hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            hipLaunchKernelGGL(kc, dim3(w / (2 * p.CB), nt), dim3(512), sh, s, w, h, p.logw, p.logh, p.CB, scale * scale, twh, spec);
-        }
-        {
-            auto ki = pad_rows ? xc_rows_inv_abs<true> : xc_rows_inv_abs<false>;
-            hipLaunchKernelGGL(ki, dim3(h / p.RBw, nt), dim3(256), sh_rows, s, w, h, p.logw, p.RBw, scale,
-                               tww, spec, surf, minmax);
-        }
-        if (nbands > 1)
-            hipLaunchKernelGGL(xc_band_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, N, minmax, surf, prod, band == 0);
+        if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
+        int rcp = launch_blur_stages(ctx, s, w, h, ntk, minmax_p, fsurf_p, tmp_p, nbands > 1, dog_dbg ? dog_dbg + (size_t)toff * N : nullptr, keys_p);
+        if (rcp) return rcp;
+        hipLaunchKernelGGL(xc_finish, dim3((ntk + 63) / 64), dim3(64), 0, s, ntk, w, h, keys_p, minmax_p, fsurf_p, d_out + tile0 + toff);
+        MIS_HIP(ctx, hipGetLastError());
+        return MIS_OK;
+    };
+    // A batch is a chain of dependent launches, each with a tail and a start-up of its own: two halves on two streams
+    // overlap them.  Small batches stay whole (a half must still fill the machine).
+    if (nt < 64) return part(0, nt, ctx->stream);
+    if (!ws->side) {
+        MIS_HIP(ctx, hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
+        MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
+        MIS_HIP(ctx, hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming));
     }
-    if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
-    rc = launch_blur_stages(ctx, w, h, nt, minmax, fsurf, tmp, nbands > 1, dog_dbg, keys);
-    if (rc) return rc;
-    hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, fsurf, d_out + tile0);
-    MIS_HIP(ctx, hipGetLastError());
-    return MIS_OK;
+    MIS_HIP(ctx, hipEventRecord(ws->ev_fork, ctx->stream));
+    MIS_HIP(ctx, hipStreamWaitEvent(ws->side, ws->ev_fork, 0));
+    const int half = nt / 2;
+    rc = part(0, half, ctx->stream);
+    const int rc2 = part(half, nt - half, ws->side);
+    // joined whatever happened: nothing of this call stays behind on the side stream
+    MIS_HIP(ctx, hipEventRecord(ws->ev_join, ws->side));
+    MIS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ws->ev_join, 0));
+    return rc ? rc : rc2;
 }
 
 // general-size variant of run_batch: stages 1-3 by row DFTs and transposes, stages 4-6 shared
@@ -1410,7 +1453,8 @@ static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1
             hipLaunchKernelGGL(xc_band_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, N, minmax, surf, prod, band == 0);
     }
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
-    rc = launch_blur_stages(ctx, w, h, nt, minmax, fsurf, tmp, nbands > 1, dog_dbg, keys);
+    rc = ensure_taps(ctx, w, h); if (rc) return rc;
+    rc = launch_blur_stages(ctx, ctx->stream, w, h, nt, minmax, fsurf, tmp, nbands > 1, dog_dbg, keys);
     if (rc) return rc;
     hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, fsurf, d_out + tile0);
     MIS_HIP(ctx, hipGetLastError());
