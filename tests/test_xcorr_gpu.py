@@ -148,6 +148,9 @@ def test_large_tile_2048(ctx):
     (200, 200, -25, 31),
     (8, 12, 1, -1),        # narrower than the blur radius: multiple reflections
     (300, 1, 5, 0),        # one row: the blur kernel collapses in that dimension
+    (160, 96, 9, -7),      # sides that are multiples of 32: the Gaussian passes run on the matrix cores
+    (32, 32, 2, 1),        # ... the smallest such tile (three reflections of a 32-sample line)
+    (1024, 64, -30, 3),    # ... and the widest line their LDS image holds
 ])
 def test_find_offset_general_sizes(ctx, w, h, dx, dy):
     """Tile sides that are not powers of two (the first level of image3.cpp's recursion works on the
