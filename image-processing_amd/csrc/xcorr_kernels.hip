@@ -178,10 +178,10 @@ __device__ __forceinline__ void fft_dif_pass(float2* x, int logn, int cnt, int l
     constexpr int M = 1 << S;
     const int l_lo = l_hi - S + 1;
     const int n = 1 << logn;
-    const int gps = n >> S;                        // groups per sequence
+    const int gps = n >> S, lgps = logn - S;       // groups per sequence
     const int groups = cnt * gps;
     for (int g = threadIdx.x; g < groups; g += NT) {
-        const int seq = g / gps, gi = g - seq * gps;
+        const int seq = g >> lgps, gi = g & (gps - 1);       // gps is a power of two
         const int low = gi & ((1 << l_lo) - 1), high = gi >> l_lo;
         const int i0 = (high << (l_hi + 1)) + low;            // index of element m = 0 inside the sequence
         const int b0 = seq * n + i0;
@@ -228,11 +228,11 @@ __device__ __forceinline__ void fft_dif_pass8(float2* x, int logn, int cnt, int 
 {
     const int l_lo = l_hi - 2;
     const int n = 1 << logn;
-    const int gps = n >> 3;
+    const int gps = n >> 3, lgps = logn - 3;
     const int groups = cnt * gps;
     const int sh = logn - 1 - l_hi;
     for (int g = threadIdx.x; g < groups; g += NT) {
-        const int seq = g / gps, gi = g - seq * gps;
+        const int seq = g >> lgps, gi = g & (gps - 1);       // gps is a power of two
         const int low = gi & ((1 << l_lo) - 1), high = gi >> l_lo;
         const int b0 = seq * n + (high << (l_hi + 1)) + low;
         float2 v[8];
@@ -282,11 +282,11 @@ __device__ __forceinline__ void fft_dit_pass8(float2* x, int logn, int cnt, int 
 {
     const int l_hi = l_lo + 2;
     const int n = 1 << logn;
-    const int gps = n >> 3;
+    const int gps = n >> 3, lgps = logn - 3;
     const int groups = cnt * gps;
     const int sh = logn - 1 - l_hi;
     for (int g = threadIdx.x; g < groups; g += NT) {
-        const int seq = g / gps, gi = g - seq * gps;
+        const int seq = g >> lgps, gi = g & (gps - 1);       // gps is a power of two
         const int low = gi & ((1 << l_lo) - 1), high = gi >> l_lo;
         const int b0 = seq * n + (high << (l_hi + 1)) + low;
         float2 v[8];
@@ -349,10 +349,10 @@ __device__ __forceinline__ void fft_dit_pass(float2* x, int logn, int cnt, int l
     constexpr int M = 1 << S;
     const int l_hi = l_lo + S - 1;
     const int n = 1 << logn;
-    const int gps = n >> S;
+    const int gps = n >> S, lgps = logn - S;
     const int groups = cnt * gps;
     for (int g = threadIdx.x; g < groups; g += NT) {
-        const int seq = g / gps, gi = g - seq * gps;
+        const int seq = g >> lgps, gi = g & (gps - 1);       // gps is a power of two
         const int low = gi & ((1 << l_lo) - 1), high = gi >> l_lo;
         const int i0 = (high << (l_hi + 1)) + low;
         const int b0 = seq * n + i0;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(512) void xc_cols(int w, int h, int logw, int logh,
     fft_dit_inv<512, PAD>(A, logh, 2 * CB, stw);
     for (int i = threadIdx.x; i < 2 * CB * h; i += 512) {
         const int q = i >= nB ? 1 : 0, ii = i - q * nB;
-        const int r = ii / CB, c = ii % CB;
+        const int r = ii >> logcb, c = ii & (CB - 1);
         sa[(size_t)r * w + c0q[q] + c] = A[xp<PAD>(q * nB + c * h + r)];
     }
 }
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, i
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int i = min(base + (int)threadIdx.x + 256 * u, n4 - 1);
-                const int p = i / (w >> 1), c = i - p * (w >> 1);
+                const int p = i >> (logw - 1), c = i & ((w >> 1) - 1);       // w is a power of two here
                 va[u] = in4[(size_t)(2 * p) * (w >> 1) + c];
                 vb[u] = in4[(size_t)(2 * p + 1) * (w >> 1) + c];
             }
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void xc_rows_inv_abs(int w, int h, int logw, i
             for (int u = 0; u < 4; u++) {
                 const int i = base + (int)threadIdx.x + 256 * u;
                 if (i < n4) {
-                    const int p = i / (w >> 1), c = i - p * (w >> 1);
+                    const int p = i >> (logw - 1), c = i & ((w >> 1) - 1);       // w is a power of two here
                     x[xp<PAD>(p * w + 2 * c)] = make_float2(va[u].x - vb[u].y, va[u].y + vb[u].x);
                     x[xp<PAD>(p * w + 2 * c + 1)] = make_float2(va[u].z - vb[u].w, va[u].w + vb[u].z);
                 }
