@@ -66,9 +66,13 @@ def entry(prefix, label):
 entry("ncc_mfma_argmax_kernel", "ncc_mfma_argmax_kernel")
 entry("ncc_argmax_kernel", "ncc_argmax_kernel")
 entry("ncc16_argmax_kernel", "ncc16_argmax_kernel")
-# one batch of the FFT tile correlation = one launch of each xc_* kernel
-xb = sum((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 for k, v in res.items() if k.startswith("xc_"))
-j["xcorr_batch"] = {"bytes": xb, "source": "profiles/%s_pmc_hbm_traffic.csv" % rnd, "note": "sum over the xc_* kernels of one batch of 256 tiles of 512x512 (raw FETCH_SIZE + WRITE_SIZE)"}
+# one batch of the FFT tile correlation: bench.py's path_f leg runs XC_BATCHES batches (2 warm-up + 10 timed), each as
+# one or two launches of every xc_* kernel (a batch of 64 tiles or more runs as two halves on two streams)
+XC_BATCHES = 12
+xb = sum((v.get("FETCH_SIZE", 0) * v.get("launches_FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0) * v.get("launches_WRITE_SIZE", 0)) * 1024 / XC_BATCHES
+         for k, v in res.items() if k.startswith("xc_"))
+j["xcorr_batch"] = {"bytes": xb, "source": "profiles/%s_pmc_hbm_traffic.csv" % rnd,
+                    "note": "all xc_* launches of the run (raw FETCH_SIZE + WRITE_SIZE) / %d batches of 256 tiles of 512x512" % XC_BATCHES}
 # the whole 8-bit step: every ncc_* kernel of one step
 st = {c: sum(v.get(c, 0) * 1024 * (v.get("launches_" + c, 1)) for k, v in res.items() if k.startswith("ncc_")) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 j["ncc_step"] = {"fetch_bytes_raw": st["FETCH_SIZE"], "write_bytes": st["WRITE_SIZE"], "bytes": st["FETCH_SIZE"] + st["WRITE_SIZE"],
