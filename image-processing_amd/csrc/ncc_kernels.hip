@@ -772,9 +772,12 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     float sec = -1.0e30f;                          // WANT2: best second-peak candidate so far (argmax-kernel scale)
     int xd = 0;                                    // WANT2: +2 / -2 when the disparity two away needs its exact score
     const size_t plane = (size_t)a.H * a.out_pitch;
+    constexpr int NKB = MF ? 6 : NCC_REFINE_KEY_BATCH;  // planes per round trip (independent loads; +-256 is 6 ranges or 9 chunks)
+    float kfirst[NKB];                             // WANT2 on matrix-core planes: the first NKB keys, kept for the second-peak pass
+#pragma unroll
+    for (int i = 0; i < NKB; i++) kfirst[i] = 0.f;
     if (inside) {
         float best = -1.0e30f;                     // below any score, above the bias of masked lanes
-        constexpr int NKB = MF ? 6 : NCC_REFINE_KEY_BATCH;  // planes per round trip (independent loads; +-256 is 6 ranges or 9 chunks)
         for (int c0 = 0; c0 < nchunk; c0 += NKB) {
             float k4[NKB];
 #pragma unroll
@@ -793,6 +796,7 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
                     if (v > best) { best = v; ds = dc; alt = MIS_INVALID_DISP; }
                     else if (v == best && alt == MIS_INVALID_DISP) alt = dc;
                 }
+                if (WANT2 && MF && c0 == 0) kfirst[i] = k4[i];
             }
         }
         if (oIdisp) oIdisp[o] = (int16_t)ds;       // rewritten below where the exact scores pick the other candidate
@@ -947,6 +951,26 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
         // also leaves out the column two away from the winner: that one's exact score is computed below.
         constexpr int RW = 32 * range_tiles;
         const int tt = a.dmax + ((x - R) & 63) - ds, ps = tt / RW, js = tt % RW;
+        // plane c was key number nchunk - 1 - c of the merge above
+        if (nchunk <= NKB) {
+            int cs = -1;                               // the neighbouring plane whose second key is needed, if any
+#pragma unroll
+            for (int i = 0; i < NKB; i++) {
+                const int c = nchunk - 1 - i;
+                if (c < 0) continue;
+                const uint32_t kb = __builtin_bit_cast(uint32_t, kfirst[i]);
+                const int jr = (int)(kb & 127u);
+                if (c == ps) continue;
+                if (c == ps - 1 && js == 0 && jr == RW - 1) { cs = c; xd = 2; continue; }
+                if (c == ps + 1 && js == RW - 1 && jr == 0) { cs = c; xd = -2; continue; }
+                const float v = __builtin_bit_cast(float, kb & 0xFFFFFF80u);
+                if (v > sec) sec = v;
+            }
+            const float v0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, gKeys2[(size_t)ps * plane + o]) & 0xFFFFFF80u);
+            const float v1 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, gKeys2[(size_t)(cs >= 0 ? cs : ps) * plane + o]) & 0xFFFFFF80u);
+            if (v0 > sec) sec = v0;
+            if (v1 > sec) sec = v1;
+        } else
         for (int c = 0; c < nchunk; c++) {
             const uint32_t kb = __builtin_bit_cast(uint32_t, gKeys[(size_t)c * plane + o]);
             const int jr = (int)(kb & 127u);
