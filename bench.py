@@ -574,7 +574,10 @@ def main():
                                "note": "correspondences with peak >= 0.75 triangulated to XYZ; rate = points / (correlation step + triangulation)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic_note(kname),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/ (not measured in this run)",
+                         "traffic_fetch_doubled": (2 * (load_traffic_note(kname, "fetch_bytes_raw") or 0) + (load_traffic_note(kname, "write_bytes") or 0)) or None,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/ (not measured in this run); "
+                                           "traffic = FETCH_SIZE + WRITE_SIZE as reported, traffic_fetch_doubled = 2 x FETCH_SIZE + WRITE_SIZE "
+                                           "(on gfx950 FETCH_SIZE counts half the bytes of 16-byte-per-lane streaming reads, which is how these kernels stage their rows)",
                          "kernel": kname, "kernel_ms": round(kernel_s * 1e3, 4),
                          "tables_ms": round(pre_ms / max(calls, 1), 4),
                          "refine_ms": round(refine_ms / max(calls, 1), 4),
