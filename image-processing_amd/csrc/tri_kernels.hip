@@ -185,7 +185,8 @@ __device__ __forceinline__ bool tri_fast_ok(float ang1z, float ang2z, float z0)
 {
     const float lo = 9.5367431640625e-07f, hi = 1048576.0f;
     const float b = fabsf(ang2z);
-    return b >= lo && b <= hi && fabsf(ang1z) <= hi && fabsf(z0) <= 4.0f * hi;   // false for NaN
+    // z0: anything below the 2^25 at which the caller's own special case takes over keeps |w1z - t2z| below 2^46
+    return b >= lo && b <= hi && fabsf(ang1z) <= hi && fabsf(z0) < 33554432.0f;   // false for NaN
 }
 
 // image3.cpp:148-264 for one point

@@ -153,3 +153,22 @@ def test_two_million_points_over_random_geometries(ctx):
         nan = np.isnan(want)
         assert np.array_equal(np.isnan(got), nan), "geometry %d" % g
         assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan]), "geometry %d" % g
+
+
+@pytest.mark.parametrize("d", [1.0, -1.0, 2.0, -3.0, 7.0, 20.0])
+def test_nearly_parallel_rays(ctx, d):
+    """Small disparities against a long baseline: the rays are all but parallel, the secant start of the search lies
+    millions of units away and both of the reference's searches run their hundred steps past the minimum
+    (image3.cpp:220-246).  Bit for bit against the oracle on every pixel of a constant-disparity raster."""
+    import torch
+    h, w = 24, 160
+    c1, c2 = _cameras(w, h, 900.0)
+    left = np.zeros((h, w), np.uint8)
+    ctx.bind_pair_torch(_to_cuda(left), _to_cuda(left))
+    disp = torch.full((h, w), d, dtype=torch.float32, device="cuda")
+    peak = torch.ones((h, w), dtype=torch.float32, device="cuda")
+    xyz = torch.full((h, w, 3), 7.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    n = ctx.triangulate_disparity_torch(mistereo.make_camera(*c1), mistereo.make_camera(*c2), disp, peak, MIN_PEAK, xyz)
+    ctx.synchronize()
+    assert _check(disp.cpu().numpy(), peak.cpu().numpy(), xyz.cpu().numpy(), n, c1, c2) == h * w
