@@ -336,8 +336,10 @@ def bench_ncc16(ctx, stream, dev, steps=3, cpu=True):
     idisp = torch.empty((H, W), dtype=torch.int16, device=dev)
     xyz = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     A = [[10000.0, 0.0, W / 2.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
+    # second principal point offset by f B / H = 3000 px (the offset between the two crops): the 37.25 px shift is relief
+    A2 = [[10000.0, 0.0, W / 2.0 + 3000.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
     cam1 = mistereo.make_camera(A, np.eye(3), [0.0, 0.0, -3000.0])
-    cam2 = mistereo.make_camera(A, np.eye(3), [-900.0, 0.0, -3000.0])
+    cam2 = mistereo.make_camera(A2, np.eye(3), [-900.0, 0.0, -3000.0])
     torch.cuda.synchronize()
     with torch.cuda.stream(stream):
         ctx.bind_pair_torch(tl, tr)
@@ -528,10 +530,14 @@ def main():
         dp, pk = last_result(args.steps)
         # every matched pixel (peak >= 0.75, the reference's accept threshold image3.cpp:751) triangulated to XYZ
         # (calculateXYZ, image3.cpp:148-264) with two synthetic nadir cameras (f = 10000 px, height 3000 m,
-        # baseline 900 m, R = I), timed on its own, outside the timed region
+        # baseline 900 m, R = I), timed on its own, outside the timed region.  The second camera's principal point
+        # carries the f B / H = 3000 px between the origins of the two crops, so that the pair's disparities of
+        # +-200 px are +-200 m of relief around z = 0 (a crop pair whose disparities straddle zero has such an offset).
         A = [[10000.0, 0.0, W / 2.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
+        A2 = [[10000.0, 0.0, W / 2.0 + 10000.0 * 900.0 / 3000.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
         cam1 = mistereo.make_camera(A, np.eye(3), [0.0, 0.0, -3000.0])
-        cam2 = mistereo.make_camera(A, np.eye(3), [-900.0, 0.0, -3000.0])
+        cam2 = mistereo.make_camera(A2, np.eye(3), [-900.0, 0.0, -3000.0])
+        cam2_same_pp = mistereo.make_camera(A, np.eye(3), [-900.0, 0.0, -3000.0])
         xyz = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
         n_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
@@ -539,6 +545,12 @@ def main():
             # the raster size is passed in: in the strips partition rank 0's bound raster is its strip only
             ctx.triangulate_disparity_noalloc_torch(cam1, cam2, dp, pk, 0.75, xyz, n_dev)      # warm-up
             stream.synchronize()
+            # the same with one principal point for both cameras: the rays are then nearly parallel and the
+            # reference's search (image3.cpp:220-246) runs hundreds of steps per point
+            t_par = time.perf_counter()
+            ctx.triangulate_disparity_noalloc_torch(cam1, cam2_same_pp, dp, pk, 0.75, xyz, n_dev)
+            stream.synchronize()
+            t_par = time.perf_counter() - t_par
             t_tri = time.perf_counter()
             ctx.triangulate_disparity_noalloc_torch(cam1, cam2, dp, pk, 0.75, xyz, n_dev)
             stream.synchronize()
@@ -571,7 +583,10 @@ def main():
                        "gather_to_rank0": bool(do_gather)},
             "matched_points_per_s": round(matched * (1 if strips_mode else world) / (dt / max(args.steps, 1) + t_tri), 1),
             "matched_points": {"per_frame": matched, "peak_threshold": 0.75, "triangulation_ms": round(t_tri * 1e3, 3),
-                               "note": "correspondences with peak >= 0.75 triangulated to XYZ; rate = points / (correlation step + triangulation)"},
+                               "triangulation_ms_nearly_parallel_rays": round(t_par * 1e3, 3),
+                               "note": "correspondences with peak >= 0.75 triangulated to XYZ; rate = points / (correlation step + triangulation); "
+                                       "cameras: f 10000 px, height 3000 m, baseline 900 m, the second principal point offset by f B / H so that "
+                                       "the disparities are relief around z = 0; nearly_parallel_rays: the same with one principal point for both"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic_note(kname),
                          "traffic_fetch_doubled": (2 * (load_traffic_note(kname, "fetch_bytes_raw") or 0) + (load_traffic_note(kname, "write_bytes") or 0)) or None,
