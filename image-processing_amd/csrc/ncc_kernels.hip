@@ -69,11 +69,10 @@ static int ncc_fork(mis_ctx* ctx, NccWs* w)
 {
     if (w->forked) return MIS_OK;
     if (!w->side) {
-        // highest priority: its few workgroups are dispatched as soon as wave slots free up, so the
-        // side work ends long before the argmax kernel does
-        int prio_lo = 0, prio_hi = 0;
-        MIS_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        MIS_HIP(ctx, hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, prio_hi));
+        // Normal priority, like the main stream.  A high-priority side stream that waits for an event of a
+        // normal-priority stream can stall for good once a process holds more queues than the device has
+        // hardware queues (the waiting queue keeps its slot and the queue it waits for is never scheduled).
+        MIS_HIP(ctx, hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
         MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
         MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_tables, hipEventDisableTiming));
         MIS_HIP(ctx, hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
