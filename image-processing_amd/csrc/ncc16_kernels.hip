@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
     int32_t* tL = ncc16_refine_lds;               // [G][LC]
     int32_t* tR = ncc16_refine_lds + G * LC;      // [G][NC]
     const int tid = threadIdx.x;
-    const int lx = tid & (NCC16_REF_BW - 1), ly = tid / NCC16_REF_BW;
+    const int lx = tid & (NCC16_REF_BW - 1), ly = __builtin_amdgcn_readfirstlane(tid / NCC16_REF_BW);   // a wavefront is 64 pixels of one row
     const int x0 = R + blockIdx.x * NCC16_REF_BW;
     const int y0 = a.row0 + 4 * blockIdx.y;
     const int x = x0 + lx, y = y0 + ly;

@@ -757,7 +757,9 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     uint32_t* tR = ncc_refine_lds + NQ * LC;     // [NQ][NC]
 
     const int tid = threadIdx.x;
-    const int lx = tid & (NCC_REF_BW - 1), ly = tid / NCC_REF_BW;
+    // a wavefront is 64 pixels of ONE row: the row index in a scalar register keeps the window-row masks,
+    // the quad tests and the row addresses below on the scalar unit
+    const int lx = tid & (NCC_REF_BW - 1), ly = __builtin_amdgcn_readfirstlane(tid / NCC_REF_BW);
     const int x0 = R + blockIdx.x * NCC_REF_BW;
     const int y0 = a.row0 + 4 * blockIdx.y;
     const int x = x0 + lx, y = y0 + ly;
