@@ -357,17 +357,22 @@ def bench_ncc16(ctx, stream, dev, steps=3, cpu=True):
         for _ in range(steps):
             ctx.triangulate_disparity_torch(cam1, cam2, disp, peak, 0.75, xyz, count=False)
         e[2].record(stream)
+        for _ in range(steps):                              # the fractional column x - disp instead of the rounded one
+            ctx.triangulate_disparity_torch(cam1, cam2, disp, peak, 0.75, xyz, count=False, subpixel=True)
+        e3 = torch.cuda.Event(enable_timing=True)
+        e3.record(stream)
         matched = int(ctx.triangulate_disparity_torch(cam1, cam2, disp, peak, 0.75, xyz))
     stream.synchronize()
     tables_ms, main_ms, refine_ms, calls = ctx.profile_read()
     ctx.profile(False)
     ms, tri_ms = e[0].elapsed_time(e[1]) / steps, e[1].elapsed_time(e[2]) / steps
+    tri_sub_ms = e[2].elapsed_time(e3) / steps
     kernel_ms = main_ms / max(calls, 1)
     alg = ALG_BYTES_PER_PX_U16 * H * W
     res = {
         "workload": "BASELINE config[4] band: %dx%d 16-bit, %dx%d window, +-%d px (%d disparities), subpixel + XYZ" % (W, H, win, win, D, nd),
         "ms_per_step": round(ms, 3), "gpx_disp_per_s": round(H * W * nd / ms / 1e6, 2),
-        "triangulation_ms": round(tri_ms, 3), "matched_points": matched,
+        "triangulation_ms": round(tri_ms, 3), "triangulation_subpixel_columns_ms": round(tri_sub_ms, 3), "matched_points": matched,
         "matched_points_per_s": round(matched / (ms + tri_ms) * 1e3, 1),
         "roofline": {"bound": "hbm", "kernel": "ncc16_argmax_kernel", "kernel_ms": round(kernel_ms, 3),
                      "tables_ms": round(tables_ms / max(calls, 1), 3), "refine_ms": round(refine_ms / max(calls, 1), 3),

@@ -66,11 +66,14 @@ __device__ __forceinline__ float xyz2(const float* ang1, const float* t1p, const
     return err;
 }
 
-// rotate the pixel ray into world coordinates: gemm with double accumulation (image3.cpp:185-199)
-__device__ __forceinline__ void ray(const TriCam& c, int u, int v, float* ang)
+// rotate the pixel ray into world coordinates: gemm with double accumulation (image3.cpp:185-199).
+// The reference's integer pixel coordinates are converted to float where they meet the principal point
+// (usual arithmetic conversion of `u1 - cx1`); they arrive here converted, which also admits a
+// fractional column.
+__device__ __forceinline__ void ray(const TriCam& c, float u, float v, float* ang)
 {
-    float a0 = ((float)u - c.cx) / c.fx;
-    float a1 = -((float)v - c.cy) / c.fy;
+    float a0 = (u - c.cx) / c.fx;
+    float a1 = -(v - c.cy) / c.fy;
     float a2 = -1.0f;
     for (int i = 0; i < 3; i++) {
         double s = 0.0;                          // the accumulator starts at +0 (sign of a zero result)
@@ -191,7 +194,7 @@ __device__ __forceinline__ bool tri_fast_ok(float ang1z, float ang2z, float z0)
 
 // image3.cpp:148-264 for one point
 __device__ void triangulate_point(const TriCam& c1, const TriCam& c2, bool cams_fast,
-                                       int u1, int v1, int u2, int v2, float& X, float& Y, float& Z)
+                                       float u1, float v1, float u2, float v2, float& X, float& Y, float& Z)
 {
     TriFast r;
     ray(c1, u1, v1, r.a1);
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void tri_points_kernel(TriCam c1, TriCam c2, b
     if (i >= n) return;
     int4 p = pts[i];
     float X, Y, Z;
-    triangulate_point(c1, c2, cams_fast, p.x, p.y, p.z, p.w, X, Y, Z);
+    triangulate_point(c1, c2, cams_fast, (float)p.x, (float)p.y, (float)p.z, (float)p.w, X, Y, Z);
     xyz[3 * (size_t)i] = X; xyz[3 * (size_t)i + 1] = Y; xyz[3 * (size_t)i + 2] = Z;
 }
 
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void tri_points_kernel(TriCam c1, TriCam c2, b
 __global__ __launch_bounds__(256) void tri_disparity_kernel(TriCam c1, TriCam c2, bool cams_fast,
                                                             const float* __restrict__ disp,
                                                             const float* __restrict__ peak, float min_peak,
-                                                            int W, int H, float* __restrict__ xyz,
+                                                            bool subpixel, int W, int H, float* __restrict__ xyz,
                                                             unsigned long long* __restrict__ count)
 {
     int x = blockIdx.x * 256 + threadIdx.x;
@@ -307,8 +310,10 @@ __global__ __launch_bounds__(256) void tri_disparity_kernel(TriCam c1, TriCam c2
         float d = disp[o];
         ok = (d != (float)MIS_INVALID_DISP) && (peak[o] >= min_peak);
         if (ok) {
-            int u2 = x - (int)rintf(d);
-            triangulate_point(c1, c2, cams_fast, x, y, u2, y, X, Y, Z);
+            // the reference hands integer pixels to calculateXYZ (image3.cpp:812-824): the disparity is rounded;
+            // subpixel: the fractional column x - d goes into the same arithmetic
+            const float u2 = subpixel ? (float)x - d : (float)(x - (int)rintf(d));
+            triangulate_point(c1, c2, cams_fast, (float)x, (float)y, u2, (float)y, X, Y, Z);
         }
         xyz[3 * o] = X; xyz[3 * o + 1] = Y; xyz[3 * o + 2] = Z;
     }
@@ -406,10 +411,18 @@ int mis_triangulate_disparity_device(mis_ctx* ctx, const mis_camera* c1, const m
                                      const float* d_disp, const float* d_peak, float min_peak,
                                      float* d_xyz, long long* n_matched)
 {
+    return mis_triangulate_disparity_ex_device(ctx, c1, c2, d_disp, d_peak, min_peak, 0, d_xyz, n_matched);
+}
+
+int mis_triangulate_disparity_ex_device(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                                        const float* d_disp, const float* d_peak, float min_peak, int flags,
+                                        float* d_xyz, long long* n_matched)
+{
     int rc = tri_check(ctx, c1, c2);
     if (rc) return rc;
     if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "triangulate: no image pair bound (raster size unknown)");
     if (!d_disp || !d_peak || !d_xyz) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: NULL buffer");
+    if (flags & ~MIS_TRI_SUBPIXEL) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: unknown flags 0x%x", flags);
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t cnt_bytes = (size_t)TRI_COUNT_SLOTS * 128;
     rc = mis_reserve(ctx, &ctx->tri_buf, &ctx->tri_bytes, cnt_bytes);
@@ -419,7 +432,7 @@ int mis_triangulate_disparity_device(mis_ctx* ctx, const mis_camera* c1, const m
     TriCam a = make_cam(c1), b = make_cam(c2);
     const int W = ctx->width, H = ctx->height;
     hipLaunchKernelGGL(tri_disparity_kernel, dim3((W + 255) / 256, H), dim3(256), 0, ctx->stream, a, b,
-                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, W, H, d_xyz, cnt);
+                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, (flags & MIS_TRI_SUBPIXEL) != 0, W, H, d_xyz, cnt);
     MIS_HIP(ctx, hipGetLastError());
     if (n_matched) {
         unsigned long long h[TRI_COUNT_SLOTS * 16];
@@ -452,7 +465,7 @@ int mis_triangulate_disparity_noalloc(mis_ctx* ctx, const mis_camera* c1, const 
     MIS_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)TRI_COUNT_SLOTS * 128, ctx->stream));
     TriCam a = make_cam(c1), b = make_cam(c2);
     hipLaunchKernelGGL(tri_disparity_kernel, dim3((width + 255) / 256, height), dim3(256), 0, ctx->stream, a, b,
-                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, width, height, d_xyz, cnt);
+                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, false, width, height, d_xyz, cnt);
     if (d_n_matched)
         hipLaunchKernelGGL(tri_count_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt, d_n_matched);
     MIS_HIP(ctx, hipGetLastError());

@@ -53,7 +53,7 @@ EXPORTS = [
     "mis_xcorr_tiles", "mis_xcorr_tiles_device", "mis_xcorr_tile_surfaces",
     "mis_fft2d_forward", "mis_xcorr_surface_u8",
     "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
-    "mis_triangulate_disparity_noalloc",
+    "mis_triangulate_disparity_noalloc", "mis_triangulate_disparity_ex_device",
     "mis_disparity_map", "mis_write_xyz", "mis_write_xyz_ex", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
     "mis_set_extra_bands_device", "mis_upload_extra_bands", "mis_masked_peak",
     "mis_profile_enable", "mis_profile_read", "mis_version",
@@ -105,6 +105,7 @@ def load_library():
         lib.mis_profile_enable.argtypes = [vp, i32]
         lib.mis_profile_read.argtypes = [vp, vp, vp, vp, vp]
         lib.mis_triangulate_disparity_device.argtypes = [vp, vp, vp, vp, vp, f32, vp, vp]
+        lib.mis_triangulate_disparity_ex_device.argtypes = [vp, vp, vp, vp, vp, f32, i32, vp, vp]
         lib.mis_triangulate_disparity_noalloc.argtypes = [vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]
         _lib = lib
     return _lib
@@ -139,6 +140,7 @@ def make_camera(A, R, T):
 
 
 XYZ_APPEND, XYZ_REF_TRUNCATE = 1, 2
+TRI_SUBPIXEL = 1
 
 
 def write_xyz(path, xyz, bands=None, append=False, ref_truncate=False):
@@ -403,11 +405,18 @@ class Context:
                                               _np_ptr(out)))
         return out
 
-    def triangulate_disparity_torch(self, cam1, cam2, disp, peak, min_peak, xyz, count=True):
+    def triangulate_disparity_torch(self, cam1, cam2, disp, peak, min_peak, xyz, count=True, subpixel=False):
+        """subpixel: the fractional column x - disp goes into calculateXYZ's arithmetic instead of the
+        rounded one (MIS_TRI_SUBPIXEL; the reference only triangulates integer pixels)."""
         n = C.c_longlong(0)
-        self._check(self._lib.mis_triangulate_disparity_device(self._h, C.byref(cam1), C.byref(cam2), _dev_ptr(disp),
-                                                               _dev_ptr(peak), C.c_float(min_peak), _dev_ptr(xyz),
-                                                               C.byref(n) if count else None))
+        if subpixel:
+            self._check(self._lib.mis_triangulate_disparity_ex_device(self._h, C.byref(cam1), C.byref(cam2), _dev_ptr(disp),
+                                                                      _dev_ptr(peak), C.c_float(min_peak), TRI_SUBPIXEL,
+                                                                      _dev_ptr(xyz), C.byref(n) if count else None))
+        else:
+            self._check(self._lib.mis_triangulate_disparity_device(self._h, C.byref(cam1), C.byref(cam2), _dev_ptr(disp),
+                                                                   _dev_ptr(peak), C.c_float(min_peak), _dev_ptr(xyz),
+                                                                   C.byref(n) if count else None))
         return n.value if count else None
 
     def triangulate_disparity_noalloc_torch(self, cam1, cam2, disp, peak, min_peak, xyz, n_matched=None):

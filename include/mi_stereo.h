@@ -175,6 +175,17 @@ int mis_triangulate_disparity_device(mis_ctx* ctx, const mis_camera* c1, const m
                                      const float* d_disp, const float* d_peak, float min_peak,
                                      float* d_xyz, long long* n_matched);
 
+/* Same with flags.  MIS_TRI_SUBPIXEL: the second image's column is the fractional x - disp instead of
+ * x - round(disp); everything else is calculateXYZ's arithmetic unchanged (the pixel coordinates enter
+ * it only through `(u - cx) / fx`, image3.cpp:185-194).  The reference itself only ever triangulates
+ * integer pixels (calculateXYZ takes ints, image3.cpp:148, 812-824), so this form has no counterpart
+ * there: it equals the flag-less form bit for bit wherever disp is an integer, and is checked against
+ * the same arithmetic on float coordinates elsewhere. */
+#define MIS_TRI_SUBPIXEL 1
+int mis_triangulate_disparity_ex_device(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                                        const float* d_disp, const float* d_peak, float min_peak, int flags,
+                                        float* d_xyz, long long* n_matched);
+
 /* No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same computation as
  * mis_triangulate_disparity_device, but the raster size is passed in (no pair needs to be bound), the

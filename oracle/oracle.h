@@ -83,6 +83,9 @@ void orc_fft2shift_u8(uint8_t* x, int rows, int cols);
 /* ---- triangulation (image3.cpp:102-132, 148-264) ---- */
 void orc_triangulate(const orc_camera* c1, const orc_camera* c2,
                      const int32_t* u1v1u2v2, int n, float* xyz);
+/* float pixel coordinates (no counterpart in the reference; equals orc_triangulate on integer values) */
+void orc_triangulate_f(const orc_camera* c1, const orc_camera* c2,
+                       const float* u1v1u2v2, int n, float* xyz);
 
 /* ---- hierarchical driver (image3.cpp:676-865), depth-first like the reference ---- */
 typedef struct {

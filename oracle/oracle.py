@@ -295,6 +295,14 @@ def triangulate(cam1, cam2, pts):
     return out
 
 
+def triangulate_f(cam1, cam2, pts):
+    """float pixel coordinates (u1, v1, u2, v2); equals triangulate() on integer values"""
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 4)
+    out = np.empty((pts.shape[0], 3), np.float32)
+    lib().orc_triangulate_f(C.byref(cam1), C.byref(cam2), _ptr(pts), pts.shape[0], _ptr(out))
+    return out
+
+
 def disparity_map(img1, img2, min_size=32, precision=0, max_leaves=1 << 16):
     img1 = np.ascontiguousarray(img1)
     img2 = np.ascontiguousarray(img2)

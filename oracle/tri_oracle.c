@@ -57,8 +57,10 @@ static float xyz2(const float* ang1, const float* t1p, const float* ang2, const 
     return err;
 }
 
-/* image3.cpp:148-264 */
-static void xyz(const orc_camera* c1, const orc_camera* c2, int u1, int v1, int u2, int v2,
+/* image3.cpp:148-264.  The reference takes integer pixel coordinates and converts each to float where
+ * it is used (image3.cpp:185-194); the coordinates arrive here already converted, so that the same
+ * arithmetic also serves fractional columns (orc_triangulate_f). */
+static void xyz(const orc_camera* c1, const orc_camera* c2, float u1, float v1, float u2, float v2,
                 float* X, float* Y, float* Z)
 {
     float R1p[9], R2p[9], t1p[3], t2p[3];
@@ -66,8 +68,8 @@ static void xyz(const orc_camera* c1, const orc_camera* c2, int u1, int v1, int 
     inv3(c2->R, R2p); matvec(R2p, c2->T, -1.0, t2p);
     float fx1 = c1->A[0], fy1 = c1->A[4], cx1 = c1->A[2], cy1 = c1->A[5];
     float fx2 = c2->A[0], fy2 = c2->A[4], cx2 = c2->A[2], cy2 = c2->A[5];
-    float a1[3] = { ((float)u1 - cx1) / fx1, -((float)v1 - cy1) / fy1, -1.0f };  /* image3.cpp:185-194 */
-    float a2[3] = { ((float)u2 - cx2) / fx2, -((float)v2 - cy2) / fy2, -1.0f };
+    float a1[3] = { (u1 - cx1) / fx1, -(v1 - cy1) / fy1, -1.0f };  /* image3.cpp:185-194 */
+    float a2[3] = { (u2 - cx2) / fx2, -(v2 - cy2) / fy2, -1.0f };
     float ang1[3], ang2[3];
     matvec(R1p, a1, 1.0, ang1);
     matvec(R2p, a2, 1.0, ang2);
@@ -98,6 +100,17 @@ static void xyz(const orc_camera* c1, const orc_camera* c2, int u1, int v1, int 
 }
 
 void orc_triangulate(const orc_camera* c1, const orc_camera* c2, const int32_t* p, int n, float* out)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < n; i++)
+        xyz(c1, c2, (float)p[4 * i], (float)p[4 * i + 1], (float)p[4 * i + 2], (float)p[4 * i + 3],
+            out + 3 * i, out + 3 * i + 1, out + 3 * i + 2);
+}
+
+/* The same for float pixel coordinates (a subpixel column in the second image).  No counterpart in the
+ * reference, whose calculateXYZ takes ints (image3.cpp:148, called with ints at 812-824): PARITY UNPINNED
+ * beyond integer-valued coordinates, where it equals orc_triangulate bit for bit. */
+void orc_triangulate_f(const orc_camera* c1, const orc_camera* c2, const float* p, int n, float* out)
 {
 #pragma omp parallel for schedule(dynamic, 64)
     for (int i = 0; i < n; i++)

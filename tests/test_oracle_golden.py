@@ -99,6 +99,17 @@ def test_triangulation_oracle_bit_exact():
         assert np.array_equal(got.view(np.uint32), z["xyz_%d" % i].view(np.uint32))
 
 
+def test_triangulation_oracle_float_coordinates_equal_the_integer_form():
+    """orc_triangulate_f is the same arithmetic on coordinates that arrive as floats: on integer values it
+    reproduces the golden vectors of the integer form bit for bit."""
+    z = np.load(os.path.join(GOLDEN, "tri_cases.npz"))
+    for i in range(2):
+        c1 = oracle.make_camera(z["A1_%d" % i], z["R1_%d" % i], z["T1_%d" % i])
+        c2 = oracle.make_camera(z["A2_%d" % i], z["R2_%d" % i], z["T2_%d" % i])
+        got = oracle.triangulate_f(c1, c2, z["pts"].astype(np.float32))
+        assert np.array_equal(got.view(np.uint32), z["xyz_%d" % i].view(np.uint32))
+
+
 def test_disparity_map_recursion_counts():
     """Zero-shift 256-px pair, min_size 32: levels 256, 128, 64 -> 1 + 4 + 16 findOffset calls,
     16 leaves (image3.cpp:751-774)."""

@@ -28,7 +28,7 @@ def _cameras(w, h, baseline):
     return (A, R, -R @ np.array([0.0, 0.0, 3000.0])), (A, R, -R @ np.array([baseline, 0.0, 3000.0]))
 
 
-def _dense_xyz(ctx, left, right, window, dmin, dmax, c1, c2, min_peak=MIN_PEAK):
+def _dense_xyz(ctx, left, right, window, dmin, dmax, c1, c2, min_peak=MIN_PEAK, subpixel=False):
     import torch
     h, w = left.shape
     tl, tr = _to_cuda(left), _to_cuda(right)
@@ -38,7 +38,8 @@ def _dense_xyz(ctx, left, right, window, dmin, dmax, c1, c2, min_peak=MIN_PEAK):
     xyz = torch.full((h, w, 3), 7.0, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     ctx.ncc_dense_torch(window, dmin, dmax, disp, peak)
-    n = ctx.triangulate_disparity_torch(mistereo.make_camera(*c1), mistereo.make_camera(*c2), disp, peak, min_peak, xyz)
+    n = ctx.triangulate_disparity_torch(mistereo.make_camera(*c1), mistereo.make_camera(*c2), disp, peak, min_peak, xyz,
+                                        subpixel=subpixel)
     ctx.synchronize()
     return disp.cpu().numpy(), peak.cpu().numpy(), xyz.cpu().numpy(), n
 
@@ -106,6 +107,45 @@ def test_u16_w31_pm512_pair_to_xyz(ctx):
     disp, peak, xyz, n = _dense_xyz(ctx, left, right, 31, -512, 512, c1, c2)
     matched = _check(disp, peak, xyz, n, c1, c2)
     assert matched > 0.3 * h * w
+
+
+def test_subpixel_columns_to_xyz(ctx):
+    """MIS_TRI_SUBPIXEL: the fractional column x - disp goes into calculateXYZ's arithmetic.  The reference
+    only triangulates integer pixels (image3.cpp:148, 812-824), so beyond integer-valued disparities this is
+    PARITY UNPINNED by the reference: checked bit for bit against the oracle's same arithmetic on float
+    coordinates, and against the flag-less form where the disparities are integers."""
+    import torch
+    h, w = 100, 1600
+    left = synth.texture(h, w, 0xC0FFEE + 5, np.uint16)
+    right = synth.shift_right_image_subpixel(left, 37.25)
+    right[:, 900:] = synth.shift_right_image_subpixel(left, -300.6)[:, 900:]
+    c1, c2 = _cameras(w, h, 900.0)
+    disp, peak, xyz, n = _dense_xyz(ctx, left, right, 31, -512, 512, c1, c2, subpixel=True)
+    ok = (disp != np.float32(mistereo.INVALID_DISP)) & (peak >= np.float32(MIN_PEAK))
+    assert n == int(ok.sum()) and n > 0.3 * h * w
+    assert np.all(np.isnan(xyz[~ok]))
+    ys, xs = np.nonzero(ok)
+    frac = disp[ys, xs] - np.rint(disp[ys, xs])
+    assert (np.abs(frac) > 0.05).mean() > 0.5                    # the case is about fractional columns
+    u2 = xs.astype(np.float32) - disp[ys, xs]                    # one float32 subtraction, as in the kernel
+    pts = np.stack([xs.astype(np.float32), ys.astype(np.float32), u2, ys.astype(np.float32)], axis=1)
+    want = oracle.triangulate_f(oracle.make_camera(*c1), oracle.make_camera(*c2), pts)
+    got = xyz[ys, xs]
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+    # integer-valued disparities: both forms give the same bits
+    rng = np.random.default_rng(11)
+    di = torch.from_numpy(rng.integers(-200, 201, (h, w)).astype(np.float32)).cuda()
+    pk = torch.ones_like(di)
+    a = torch.empty((h, w, 3), dtype=torch.float32, device="cuda"); b = torch.empty_like(a)
+    cam1, cam2 = mistereo.make_camera(*c1), mistereo.make_camera(*c2)
+    torch.cuda.synchronize()
+    na = ctx.triangulate_disparity_torch(cam1, cam2, di, pk, MIN_PEAK, a)
+    nb = ctx.triangulate_disparity_torch(cam1, cam2, di, pk, MIN_PEAK, b, subpixel=True)
+    ctx.synchronize()
+    assert na == nb == h * w
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
 def test_thresholds_and_empty_result(ctx):
