@@ -1371,8 +1371,18 @@ int mis_ncc_dense(mis_ctx* ctx, int window, int dmin, int dmax,
                   float* disp, float* peak, int16_t* idisp, float* peak2)
 {
     if (!ctx) return MIS_ERR_ARG;
+    return mis_ncc_dense_rows(ctx, window, dmin, dmax, 0, ctx->height, disp, peak, idisp, peak2);
+}
+
+int mis_ncc_dense_rows(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int nrows,
+                       float* disp, float* peak, int16_t* idisp, float* peak2)
+{
+    if (!ctx) return MIS_ERR_ARG;
     if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "dense NCC: no image pair bound");
     if (!disp || !peak) return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: disp and peak outputs are required");
+    if (row0 < 0 || nrows < 0 || row0 + nrows > ctx->height)
+        return mis_fail(ctx, MIS_ERR_ARG, "dense NCC: rows [%d,%d) outside the raster", row0, row0 + nrows);
+    if (nrows == 0) return MIS_OK;
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     const int H = ctx->height;
     const size_t n = (size_t)ctx->width * H, rowpx = (size_t)ctx->width;
@@ -1390,8 +1400,8 @@ int mis_ncc_dense(mis_ctx* ctx, int window, int dmin, int dmax,
     if (!ctx->strip_done[0])
         for (int i = 0; i < NS; i++) MIS_HIP(ctx, hipEventCreateWithFlags(&ctx->strip_done[i], hipEventDisableTiming));
     int r0[NS + 1];
-    for (int i = 0; i <= NS; i++) r0[i] = (int)((long long)H * i / NS) & ~3;
-    r0[NS] = H;
+    for (int i = 0; i <= NS; i++) r0[i] = row0 + ((int)((long long)nrows * i / NS) & ~3);
+    r0[NS] = row0 + nrows;
     for (int i = 0; i < NS && !rc; i++) {
         if (r0[i + 1] <= r0[i]) continue;
         rc = ncc_run(ctx, window, dmin, dmax, r0[i], r0[i + 1] - r0[i], dd, dp, di, dp2);

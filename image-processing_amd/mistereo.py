@@ -53,7 +53,8 @@ EXPORTS = [
     "mis_xcorr_tiles", "mis_xcorr_tiles_device", "mis_xcorr_tile_surfaces",
     "mis_fft2d_forward", "mis_xcorr_surface_u8",
     "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
-    "mis_triangulate_disparity_noalloc", "mis_triangulate_disparity_ex_device",
+    "mis_triangulate_disparity_noalloc", "mis_triangulate_disparity_ex_device", "mis_ncc_dense_rows",
+    "mis_create_group", "mis_destroy_group", "mis_group_size", "mis_group_last_error", "mis_group_ncc_dense",
     "mis_disparity_map", "mis_write_xyz", "mis_write_xyz_ex", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
     "mis_set_extra_bands_device", "mis_upload_extra_bands", "mis_masked_peak",
     "mis_profile_enable", "mis_profile_read", "mis_version",
@@ -89,6 +90,13 @@ def load_library():
         lib.mis_bind_pair_device.argtypes = [vp, vp, vp, i32, i32, i32, sz]
         lib.mis_ncc_dense.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
         lib.mis_ncc_dense_device.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+        lib.mis_ncc_dense_rows.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+        lib.mis_create_group.argtypes = [vp, i32, C.POINTER(vp)]
+        lib.mis_destroy_group.argtypes = [vp]
+        lib.mis_group_size.argtypes = [vp]
+        lib.mis_group_last_error.argtypes = [vp]
+        lib.mis_group_last_error.restype = C.c_char_p
+        lib.mis_group_ncc_dense.argtypes = [vp, vp, vp, i32, i32, i32, sz, i32, i32, i32, vp, vp, vp, vp]
         lib.mis_ncc_dense_rows_device.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
         lib.mis_xcorr_tiles.argtypes = [vp, vp, vp, i32, i32, i32, vp]
         lib.mis_xcorr_tiles_device.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -203,6 +211,55 @@ def _rects(rects):
     return arr
 
 
+class Group:
+    """Several GPUs driven by this process (mis_create_group): one context per listed device; a device
+    may be listed more than once."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._lib.mis_create_group(C.cast(ids, C.c_void_p), len(devices), C.byref(self._h))
+        if rc != 0:
+            raise MisError(rc, self._lib.mis_group_last_error(None).decode())
+
+    def close(self):
+        if self._h:
+            self._lib.mis_destroy_group(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self._lib.mis_group_size(self._h)
+
+    def ncc_dense(self, left, right, window, dmin, dmax, want_idisp=True, want_peak2=False):
+        """Dense NCC of a host pair, row strips over the group's devices; same result as Context.ncc_dense."""
+        left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
+        if left.shape != right.shape or left.dtype != right.dtype:
+            raise ValueError("the two rasters must have one shape and type")
+        h, w = left.shape
+        disp = np.empty((h, w), np.float32)
+        peak = np.empty((h, w), np.float32)
+        idisp = np.empty((h, w), np.int16) if want_idisp else None
+        peak2 = np.empty((h, w), np.float32) if want_peak2 else None
+        rc = self._lib.mis_group_ncc_dense(self._h, _np_ptr(left), _np_ptr(right), _dtype_code(left.dtype), w, h,
+                                           left.strides[0], window, dmin, dmax, _np_ptr(disp), _np_ptr(peak),
+                                           _np_ptr(idisp), _np_ptr(peak2))
+        if rc != 0:
+            raise MisError(rc, self._lib.mis_group_last_error(self._h).decode())
+        out = {"disp": disp, "peak": peak}
+        if want_idisp:
+            out["idisp"] = idisp
+        if want_peak2:
+            out["peak2"] = peak2
+        return out
+
+
 class Context:
     """One context per GPU and host thread; owns device scratch (mis_create / mis_destroy)."""
 
@@ -296,6 +353,11 @@ class Context:
         if want_peak2:
             out["peak2"] = peak2
         return out
+
+    def ncc_dense_rows(self, window, dmin, dmax, row0, nrows, disp, peak, idisp=None, peak2=None):
+        """Rows [row0, row0+nrows) into host rasters of the frame's shape (the other rows are left alone)."""
+        self._check(self._lib.mis_ncc_dense_rows(self._h, window, dmin, dmax, row0, nrows, _np_ptr(disp), _np_ptr(peak),
+                                                 _np_ptr(idisp), _np_ptr(peak2)))
 
     def ncc_dense_torch(self, window, dmin, dmax, disp, peak, idisp=None, peak2=None, row0=None, nrows=None):
         """Enqueue on the context's stream; outputs are CUDA tensors of the frame's shape."""

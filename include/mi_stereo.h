@@ -107,8 +107,29 @@ int mis_ncc_dense_device(mis_ctx* ctx, int window, int dmin, int dmax,
                          float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2);
 /* Row-strip form used when a frame is split over GPUs: only output rows [row0, row0+nrows)
  * are computed and written (outputs are still addressed as full frames). */
+int mis_ncc_dense_rows(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int nrows,
+                       float* disp, float* peak, int16_t* idisp, float* peak2);
 int mis_ncc_dense_rows_device(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int nrows,
                               float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2);
+
+/* ---- several GPUs from one host process ---------------------------------------------------------
+ * The reference is one process on one machine (its only concurrency is FFTW's thread pool,
+ * image3.cpp:974-975); rows of the dense correlation are independent, so a frame splits into row strips.
+ * A group holds one context per listed device (a device may be listed more than once).
+ * mis_group_ncc_dense: dense NCC of one host-resident pair; the output rows are split into n_dev contiguous
+ * strips (the remainder rows go to the first devices), device i is sent only its strip plus window/2 halo rows
+ * above and below, computes its rows and copies them into the caller's host rasters (one host thread per
+ * device).  Correlation windows never leave a device's rows, so the result equals mis_ncc_dense on one device
+ * bit for bit and no data moves between devices.  (Hosts that run one process per GPU use
+ * mis_ncc_dense_rows_device and gather with RCCL instead.) */
+typedef struct mis_group mis_group;
+int mis_create_group(const int* device_ids, int n_dev, mis_group** out);
+int mis_destroy_group(mis_group* grp);
+int mis_group_size(const mis_group* grp);
+const char* mis_group_last_error(const mis_group* grp);     /* grp may be NULL: last mis_create_group error */
+int mis_group_ncc_dense(mis_group* grp, const void* img1, const void* img2, int dtype,
+                        int width, int height, size_t row_stride_bytes, int window, int dmin, int dmax,
+                        float* disp, float* peak, int16_t* idisp, float* peak2);
 
 /* ---- FFT tile correlation ------------------------------------------------------------------
  * Batched findOffset (image3.cpp:346-517 with runFFT image3.cpp:318-335): for each i, the

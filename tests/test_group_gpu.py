@@ -1,0 +1,105 @@
+"""Several GPUs from one host process (mis_create_group / mis_group_ncc_dense) and the host-raster row-strip
+entry point under it (mis_ncc_dense_rows).  The reference has no counterpart (one process, image3.cpp:974-975);
+the bar is the library's own single-device result, bit for bit: a strip's correlation windows never leave the
+rows its device was sent.  One GPU serves every slot of the group here (a device may be listed more than once)."""
+import numpy as np
+import pytest
+
+import mistereo
+import oracle
+import synth
+from ncc_util import compare_ncc, flat_mask
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(h, w, dtype, seed, shift):
+    left = synth.texture(h, w, seed, dtype)
+    right = synth.shift_right_image(left, shift, fill_seed=seed + 1)
+    right[:, w // 2:] = synth.shift_right_image(left, -shift - 3, fill_seed=seed + 2)[:, w // 2:]
+    return left, right
+
+
+def _equal(a, b):
+    for k in a:
+        x, y = a[k], b[k]
+        if x.dtype == np.float32:
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), k
+        else:
+            assert np.array_equal(x, y), k
+
+
+@pytest.mark.parametrize("dtype,window,dr,ndev,h", [
+    (np.uint8, 21, 40, 3, 301),      # matrix-core kernels, strips of 101/100/100 rows
+    (np.uint8, 9, 17, 8, 100),       # strips of 13/12 rows: shorter than the window plus halo of their neighbours
+    (np.uint8, 27, 33, 2, 200),      # vector kernels (window above 21)
+    (np.uint16, 31, 70, 4, 190),
+])
+def test_group_equals_one_device(ctx, dtype, window, dr, ndev, h):
+    w = 500
+    left, right = _pair(h, w, dtype, 77, 11)
+    ctx.upload_pair(left, right)
+    one = ctx.ncc_dense(window, -dr, dr, want_idisp=True, want_peak2=True)
+    g = mistereo.Group([0] * ndev)
+    try:
+        assert len(g) == ndev
+        many = g.ncc_dense(left, right, window, -dr, dr, want_idisp=True, want_peak2=True)
+    finally:
+        g.close()
+    _equal(one, many)
+
+
+def test_group_against_the_oracle(ctx):
+    h, w = 160, 420
+    left, right = _pair(h, w, np.uint8, 5, 9)
+    g = mistereo.Group([0, 0, 0])
+    try:
+        gpu = g.ncc_dense(left, right, 15, -32, 32)
+    finally:
+        g.close()
+    ora = oracle.ncc_dense(left, right, 15, -32, 32, want_volume=True)
+    ora["flat"] = flat_mask(ora["volume"], ora["idisp"], -32)
+    compare_ncc(gpu, ora, volume=ora["volume"], dmin=-32)
+
+
+def test_more_devices_than_rows_and_tiny_frames(ctx):
+    left, right = _pair(5, 64, np.uint8, 3, 2)
+    ctx.upload_pair(left, right)
+    one = ctx.ncc_dense(3, -4, 4, want_peak2=True)
+    g = mistereo.Group([0] * 7)           # two of the seven strips are empty
+    try:
+        _equal(one, g.ncc_dense(left, right, 3, -4, 4, want_peak2=True))
+        # a frame lower than the window: every pixel invalid on one device and on many
+        ctx.upload_pair(left, right)
+        _equal(ctx.ncc_dense(9, -4, 4), g.ncc_dense(left, right, 9, -4, 4))
+    finally:
+        g.close()
+
+
+def test_host_rows_leave_other_rows_alone(ctx):
+    h, w = 120, 300
+    left, right = _pair(h, w, np.uint8, 21, 6)
+    ctx.upload_pair(left, right)
+    full = ctx.ncc_dense(11, -20, 20, want_peak2=True)
+    disp = np.full((h, w), 7.0, np.float32); peak = np.full((h, w), 7.0, np.float32)
+    idisp = np.full((h, w), 7, np.int16); peak2 = np.full((h, w), 7.0, np.float32)
+    ctx.ncc_dense_rows(11, -20, 20, 37, 41, disp, peak, idisp, peak2)
+    for got, want in ((disp, full["disp"]), (peak, full["peak"]), (idisp, full["idisp"]), (peak2, full["peak2"])):
+        assert np.array_equal(got[37:78], want[37:78])
+        assert (got[:37] == 7).all() and (got[78:] == 7).all()
+    with pytest.raises(mistereo.MisError):
+        ctx.ncc_dense_rows(11, -20, 20, 100, 30, disp, peak)
+
+
+def test_group_argument_errors():
+    with pytest.raises(mistereo.MisError):
+        mistereo.Group([])
+    with pytest.raises(mistereo.MisError):
+        mistereo.Group([4096])               # no such device
+    g = mistereo.Group([0])
+    try:
+        a = np.zeros((8, 8), np.uint8)
+        with pytest.raises(mistereo.MisError):
+            g.ncc_dense(a, a, 4, -1, 1)      # even window
+    finally:
+        g.close()
