@@ -380,6 +380,14 @@ def bench_ncc16(ctx, stream, dev, steps=3, cpu=True):
                      "frac": round(alg / kernel_ms / 1e6 / HBM_PEAK_GBS, 5), "kernel_gpx_disp_per_s": round(H * W * nd / kernel_ms / 1e6, 2),
                      "traffic": load_traffic_note("ncc16_argmax_kernel")},
     }
+    # Vector-issue floor of the 16-bit kernel: the wave64 instructions it executes (SQ_INSTS_VALU of a committed counter
+    # pass on this workload, profiles/) at 1.8 ns of SIMD time each, what the 64-bit integer, binary64 and dot
+    # instructions that make up its loop cost (tools/ubench/valu_rates64, profiles/), over 1024 SIMDs.
+    insts = load_traffic_note("ncc16_argmax_kernel", "insts_valu")
+    if insts and (W, H, win, D) == (16384, 1024, 31, 512):
+        floor_ms = insts * 1.8e-9 / 1024 * 1e3
+        res["roofline"]["issue_floor"] = {"ms": round(floor_ms, 3), "frac": round(floor_ms / kernel_ms, 3), "insts_valu": insts,
+                                          "note": "SQ_INSTS_VALU (committed counter pass, not measured in this run) x 1.8 ns / 1024 SIMDs / measured kernel time"}
     if not cpu:
         return res
     r = win // 2

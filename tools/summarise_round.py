@@ -61,6 +61,7 @@ def entry(prefix, label):
                 "launches_summed": ks,
                 "note": "FETCH_SIZE raw: the gfx950 x2 correction for 16-byte-per-lane streaming reads is not applied (the vector kernels read 4 B per lane or scalar; the matrix-core kernels stage their rows with 16-byte loads out of the L2, so their fetch figure may be low by up to 2x)",
                 "valu_busy": round(vb, 3) if vb is not None else None, "lds_active": round(la, 3) if la is not None else None,
+                "insts_valu": (acc[sq[0]]["SQ_INSTS_VALU"] / max(cnt[(sq[0], "SQ_INSTS_VALU")], 1)) if sq else None,
                 "valu_busy_of": sq[0] if sq else None,
                 "valu_busy_source": "profiles/%s_pmc_sq.csv" % rnd}
 entry("ncc_mfma_argmax_kernel", "ncc_mfma_argmax_kernel")
