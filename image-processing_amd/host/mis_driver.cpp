@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "mi_stereo.h"
+#include "mis_host.h"
 
 namespace {
 
@@ -28,12 +29,10 @@ int pow2_floor(int v) { int r = 0; while (v >>= 1) r++; return 1 << r; }
 
 }  // namespace
 
-extern "C" {
-
-int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_size,
-                      mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles)
+int mis_disparity_map_with(const MisTileEval& eval, int image_width, int image_height, int min_size,
+                           mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles)
 {
-    if (!ctx || !n_leaves || (max_leaves > 0 && !leaves) || min_size < 1) return MIS_ERR_ARG;
+    if (!n_leaves || (max_leaves > 0 && !leaves) || min_size < 1) return MIS_ERR_ARG;
     *n_leaves = 0;
     if (n_tiles) *n_tiles = 0;
     try {      // the containers below may throw (std::bad_alloc); nothing may leave the C ABI
@@ -57,7 +56,7 @@ int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_s
             std::vector<mis_rect> r1, r2;
             for (int i : kv.second) { r1.push_back(level[i].b1); r2.push_back(level[i].b2); }
             std::vector<mis_offset> o(r1.size());
-            int rc = mis_xcorr_tiles(ctx, r1.data(), r2.data(), (int)r1.size(), w, h, o.data());
+            int rc = eval(r1.data(), r2.data(), (int)r1.size(), w, h, o.data());
             if (rc) return rc;
             for (size_t k = 0; k < kv.second.size(); k++) off[kv.second[k]] = o[k];
             tiles += (int)r1.size();
@@ -124,6 +123,22 @@ int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_s
     if (n_tiles) *n_tiles = tiles;
     for (int i = 0; i < (int)out.size() && i < max_leaves; i++) leaves[i] = out[i].l;
     return MIS_OK;
+    } catch (...) {
+        return MIS_ERR_STATE;
+    }
+}
+
+extern "C" {
+
+int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_size,
+                      mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    try {
+        const MisTileEval eval = [ctx](const mis_rect* r1, const mis_rect* r2, int n, int w, int h, mis_offset* out) {
+            return mis_xcorr_tiles(ctx, r1, r2, n, w, h, out);
+        };
+        return mis_disparity_map_with(eval, image_width, image_height, min_size, leaves, max_leaves, n_leaves, n_tiles);
     } catch (...) {
         return MIS_ERR_STATE;
     }

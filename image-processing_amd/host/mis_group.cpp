@@ -4,6 +4,7 @@
 // strip's rows plus the window halo, computes the strip and copies it into the caller's rasters.
 // The reference has no counterpart (single process, image3.cpp:974-975).
 #include "mi_stereo.h"
+#include "mis_host.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -28,6 +29,23 @@ static int group_fail(mis_group* g, int code, const char* fmt, ...)
     va_end(ap);
     if (g) g->err = buf; else g_group_create_err = buf;
     return code;
+}
+
+// runs work(i) for every slot of the group, slot 0 on the calling thread; false when a thread could not be started
+template <class F>
+static bool group_parallel(int n_dev, F&& work)
+{
+    std::vector<std::thread> th;
+    bool spawned = true;
+    try {
+        th.reserve(n_dev);
+        for (int i = 1; i < n_dev; i++) th.emplace_back(work, i);
+    } catch (...) {
+        spawned = false;                          // the threads that did start are joined below
+    }
+    if (spawned) work(0);
+    for (std::thread& t : th) t.join();
+    return spawned;
 }
 
 extern "C" {
@@ -102,22 +120,61 @@ int mis_group_ncc_dense(mis_group* g, const void* img1, const void* img2, int dt
                                          idisp ? idisp + o : nullptr, peak2 ? peak2 + o : nullptr);
         rcs[i] = rc;
     };
-    {
-        std::vector<std::thread> th;
-        bool spawned = true;
-        try {
-            th.reserve(n_dev);
-            for (int i = 1; i < n_dev; i++) th.emplace_back(work, i);
-        } catch (...) {
-            spawned = false;                      // the threads that did start are joined below
-        }
-        if (spawned) work(0);
-        for (std::thread& t : th) t.join();
-        if (!spawned) return group_fail(g, MIS_ERR_DEVICE, "group dense NCC: could not start a host thread");
-    }
+    if (!group_parallel(n_dev, work)) return group_fail(g, MIS_ERR_DEVICE, "group dense NCC: could not start a host thread");
     for (int i = 0; i < n_dev; i++)
         if (rcs[i]) return group_fail(g, rcs[i], "group dense NCC: device slot %d: %s", i, mis_last_error(g->ctx[i]));
     return MIS_OK;
+}
+
+int mis_group_upload_pair(mis_group* g, const void* img1, const void* img2, int dtype,
+                          int width, int height, size_t row_stride_bytes)
+{
+    if (!g) return MIS_ERR_ARG;
+    const int n_dev = (int)g->ctx.size();
+    std::vector<int> rcs(n_dev, MIS_OK);
+    auto work = [&](int i) { rcs[i] = mis_upload_pair(g->ctx[i], img1, img2, dtype, width, height, row_stride_bytes); };
+    if (!group_parallel(n_dev, work)) return group_fail(g, MIS_ERR_DEVICE, "group upload: could not start a host thread");
+    for (int i = 0; i < n_dev; i++)
+        if (rcs[i]) return group_fail(g, rcs[i], "group upload: device slot %d: %s", i, mis_last_error(g->ctx[i]));
+    return MIS_OK;
+}
+
+int mis_group_xcorr_tiles(mis_group* g, const mis_rect* r1, const mis_rect* r2, int n,
+                          int tile_w, int tile_h, mis_offset* out)
+{
+    if (!g) return MIS_ERR_ARG;
+    if (n < 0 || (n > 0 && (!r1 || !r2 || !out))) return group_fail(g, MIS_ERR_ARG, "group tile correlation: bad tile buffers");
+    if (n == 0) return MIS_OK;
+    // contiguous shares of the batch, the remainder tiles to the first devices; a share of a few tiles is not worth
+    // a device of its own (the first levels of the recursion hold 1, 4, 16 tiles)
+    const int n_all = (int)g->ctx.size();
+    const int n_dev = n < 4 * n_all ? (n + 3) / 4 < n_all ? (n + 3) / 4 : n_all : n_all;
+    const int base = n / n_dev, rem = n % n_dev;
+    std::vector<int> rcs(n_dev, MIS_OK);
+    auto work = [&](int i) {
+        const int t0 = i * base + (i < rem ? i : rem), nt = base + (i < rem ? 1 : 0);
+        if (nt > 0) rcs[i] = mis_xcorr_tiles(g->ctx[i], r1 + t0, r2 + t0, nt, tile_w, tile_h, out + t0);
+    };
+    if (!group_parallel(n_dev, work)) return group_fail(g, MIS_ERR_DEVICE, "group tile correlation: could not start a host thread");
+    for (int i = 0; i < n_dev; i++)
+        if (rcs[i]) return group_fail(g, rcs[i], "group tile correlation: device slot %d: %s", i, mis_last_error(g->ctx[i]));
+    return MIS_OK;
+}
+
+int mis_group_disparity_map(mis_group* g, int image_width, int image_height, int min_size,
+                            mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles)
+{
+    if (!g) return MIS_ERR_ARG;
+    try {
+        const MisTileEval eval = [g](const mis_rect* r1, const mis_rect* r2, int n, int w, int h, mis_offset* out) {
+            return mis_group_xcorr_tiles(g, r1, r2, n, w, h, out);
+        };
+        const int rc = mis_disparity_map_with(eval, image_width, image_height, min_size, leaves, max_leaves, n_leaves, n_tiles);
+        if (rc && g->err.empty()) group_fail(g, rc, rc == MIS_ERR_STATE ? "group disparity map: no overlap" : "group disparity map: bad argument");
+        return rc;
+    } catch (...) {
+        return group_fail(g, MIS_ERR_STATE, "group disparity map: out of host memory");
+    }
 }
 
 }  // extern "C"

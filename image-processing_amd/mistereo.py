@@ -55,6 +55,7 @@ EXPORTS = [
     "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
     "mis_triangulate_disparity_noalloc", "mis_triangulate_disparity_ex_device", "mis_ncc_dense_rows",
     "mis_create_group", "mis_destroy_group", "mis_group_size", "mis_group_last_error", "mis_group_ncc_dense",
+    "mis_group_upload_pair", "mis_group_xcorr_tiles", "mis_group_disparity_map",
     "mis_disparity_map", "mis_write_xyz", "mis_write_xyz_ex", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
     "mis_set_extra_bands_device", "mis_upload_extra_bands", "mis_masked_peak",
     "mis_profile_enable", "mis_profile_read", "mis_version",
@@ -97,6 +98,9 @@ def load_library():
         lib.mis_group_last_error.argtypes = [vp]
         lib.mis_group_last_error.restype = C.c_char_p
         lib.mis_group_ncc_dense.argtypes = [vp, vp, vp, i32, i32, i32, sz, i32, i32, i32, vp, vp, vp, vp]
+        lib.mis_group_upload_pair.argtypes = [vp, vp, vp, i32, i32, i32, sz]
+        lib.mis_group_xcorr_tiles.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+        lib.mis_group_disparity_map.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp]
         lib.mis_ncc_dense_rows_device.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
         lib.mis_xcorr_tiles.argtypes = [vp, vp, vp, i32, i32, i32, vp]
         lib.mis_xcorr_tiles_device.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -236,6 +240,43 @@ class Group:
 
     def __len__(self):
         return self._lib.mis_group_size(self._h)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MisError(rc, self._lib.mis_group_last_error(self._h).decode())
+
+    def upload_pair(self, img1, img2):
+        """The whole pair to every device of the group (tile correlation reaches anywhere in both rasters)."""
+        img1, img2 = np.ascontiguousarray(img1), np.ascontiguousarray(img2)
+        if img1.shape != img2.shape or img1.dtype != img2.dtype or img1.ndim != 2:
+            raise ValueError("image pair must be two 2-D rasters of equal shape and type")
+        h, w = img1.shape
+        self._check(self._lib.mis_group_upload_pair(self._h, _np_ptr(img1), _np_ptr(img2), _dtype_code(img1.dtype),
+                                                    w, h, img1.strides[0]))
+        self.shape = (h, w)
+
+    def find_offsets(self, rects1, rects2, tile_w, tile_h):
+        """Context.find_offsets with the batch shared out over the group's devices."""
+        r1, r2 = _rects(rects1), _rects(rects2)
+        if r1.shape != r2.shape:
+            raise ValueError("rect lists differ in length")
+        n = r1.shape[0]
+        out = (Offset * max(n, 1))()
+        self._check(self._lib.mis_group_xcorr_tiles(self._h, _np_ptr(r1), _np_ptr(r2), n, tile_w, tile_h, out))
+        res = np.frombuffer(out, dtype=[("dx", "<i4"), ("dy", "<i4"), ("peak", "<f4"), ("dog_peak", "<f4")])
+        return res[:n].copy()
+
+    def disparity_map(self, min_size=32, max_leaves=1 << 16):
+        """Context.disparity_map with every level's tile batches shared out over the group's devices."""
+        h, w = self.shape
+        leaves = (Leaf * max_leaves)()
+        n, nt = C.c_int(0), C.c_int(0)
+        self._check(self._lib.mis_group_disparity_map(self._h, w, h, min_size, leaves, max_leaves, C.byref(n), C.byref(nt)))
+        if n.value > max_leaves:
+            return self.disparity_map(min_size, n.value)
+        recs = [(l.bbox1.minx, l.bbox1.miny, l.bbox1.width, l.bbox1.height, l.total_dx, l.total_dy,
+                 l.u1, l.v1, l.u2, l.v2, l.peak) for l in leaves[:min(n.value, max_leaves)]]
+        return recs, nt.value
 
     def ncc_dense(self, left, right, window, dmin, dmax, want_idisp=True, want_peak2=False):
         """Dense NCC of a host pair, row strips over the group's devices; same result as Context.ncc_dense."""

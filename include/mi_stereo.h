@@ -241,6 +241,18 @@ typedef struct {
 int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_size,
                       mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles);
 
+/* Tile correlation over the group.  The tiles of one recursion level are independent (a child needs only its
+ * parent's offset, image3.cpp:768-771) and reach anywhere in both rasters, so every device holds the whole pair
+ * (mis_group_upload_pair) and a batch is dealt out in contiguous shares (small batches to fewer devices).
+ * mis_group_xcorr_tiles is mis_xcorr_tiles, mis_group_disparity_map is mis_disparity_map (same leaves, same
+ * order), with every level's batches shared out this way. */
+int mis_group_upload_pair(mis_group* grp, const void* img1, const void* img2, int dtype,
+                          int width, int height, size_t row_stride_bytes);
+int mis_group_xcorr_tiles(mis_group* grp, const mis_rect* r1, const mis_rect* r2, int n,
+                          int tile_w, int tile_h, mis_offset* out);
+int mis_group_disparity_map(mis_group* grp, int image_width, int image_height, int min_size,
+                            mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles);
+
 /* XYZ text file of image3.cpp:842-849: "%f %f %f " then one "%f " per band, newline; the format
  * xyz2pcd/xyzrgb2pcd.cpp:49 and xyz2geojson (its .rb scripts) read.  bands: n x n_bands samples (nullable). */
 int mis_write_xyz(const char* path, const float* xyz, int n, const float* bands, int n_bands, int append);

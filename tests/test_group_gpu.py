@@ -91,6 +91,33 @@ def test_host_rows_leave_other_rows_alone(ctx):
         ctx.ncc_dense_rows(11, -20, 20, 100, 30, disp, peak)
 
 
+def test_group_tile_correlation_and_recursion(ctx):
+    """A level's tiles shared out over the group: the same offsets, peaks and leaves (in the same order) as on
+    one device, whatever the share sizes (1, 4 and 16 tiles go to fewer devices than 64)."""
+    h = w = 1024
+    left = synth.texture(h, w, 41)
+    right = synth.shift_right_image(left, 7, fill_seed=42)
+    rng = np.random.default_rng(3)
+    g = mistereo.Group([0, 0, 0])
+    try:
+        ctx.upload_pair(left, right)
+        g.upload_pair(left, right)
+        for n, tile in ((1, 256), (5, 128), (37, 64), (200, 32)):
+            xs = rng.integers(0, w - tile, n); ys = rng.integers(0, h - tile, n)
+            r1 = np.stack([xs, ys, np.full(n, tile), np.full(n, tile)], axis=1)
+            r2 = r1.copy(); r2[:, 0] = np.clip(r2[:, 0] - 7, 0, w - tile)
+            one, many = ctx.find_offsets(r1, r2, tile, tile), g.find_offsets(r1, r2, tile, tile)
+            assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
+        assert len(g.find_offsets(np.zeros((0, 4)), np.zeros((0, 4)), 64, 64)) == 0
+        leaves1, tiles1 = ctx.disparity_map(min_size=32)
+        leavesg, tilesg = g.disparity_map(min_size=32)
+        assert tiles1 == tilesg and len(leaves1) == len(leavesg) > 16
+        for a, b in zip(leaves1, leavesg):
+            assert a[:10] == b[:10] and np.float32(a[10]).tobytes() == np.float32(b[10]).tobytes()
+    finally:
+        g.close()
+
+
 def test_group_argument_errors():
     with pytest.raises(mistereo.MisError):
         mistereo.Group([])
