@@ -16,3 +16,12 @@ for it in range(3):
     t2 = time.perf_counter()
     print("upload %.1f ms, ncc_dense with host outputs %.1f ms, total %.1f ms -> %.1f Gpx*disp/s" % (
         (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3, size * size * (2 * D + 1) / (t2 - t0) / 1e9), flush=True)
+# the same through a group (one process over several GPUs; here every slot is GPU 0): strips in parallel host threads
+for slots in (1, 2, 4):
+    g = mistereo.Group([0] * slots)
+    for it in range(3):
+        t0 = time.perf_counter()
+        out = g.ncc_dense(left, right, win, -D, D, want_idisp=False)
+        t1 = time.perf_counter()
+    print("group of %d slot(s) on one GPU: %.1f ms -> %.1f Gpx*disp/s" % (slots, (t1 - t0) * 1e3, size * size * (2 * D + 1) / (t1 - t0) / 1e9), flush=True)
+    g.close()
