@@ -52,9 +52,15 @@ def parse(argv=None):
                     help="rows of the frame the CPU oracle is timed on (0: skip the CPU baseline)")
     ap.add_argument("--extras", choices=["on", "off"], default="on",
                     help="at N=1: also measure the FFT tile correlation and the 16-bit dense NCC")
+    ap.add_argument("--strips-leg", choices=["on", "off", "force"], default="on",
+                    help="with N>1 in the frames partition: afterwards also time rank 0's pair sharded by row strips over the "
+                         "same ranks (reported under \"strips\"); force: run that leg at N=1 too (one strip, no transfers)")
     ap.add_argument("--second-peak", choices=["on", "off"], default="on",
                     help="at N=1 with extras: also time the step with the second-peak output (off for counter passes that sum per step)")
     return ap.parse_args(argv)
+
+
+STRIPS_LEG_LIMIT_S = 150      # the strips leg and the final barrier of a multi-rank run must come back within this
 
 
 def load_traffic_note(kernel_name, field="bytes"):
@@ -200,6 +206,76 @@ class StripJob:
     def result(self, i):
         """Rank 0: the full (disparity, peak) rasters of step i."""
         return self.out[i % self.nbuf]
+
+
+def strips_leg(args, rank, world, dev, ctx, stream, H, W, D, seed, full_frame):
+    """The strips partition timed on the ranks of a frames-partition run: the pair of `seed` (rank 0's) sharded by
+    row strips with halo, every rank holding only its strip, rows sent to rank 0 as grouped point-to-point transfers.
+    full_frame: rank 0's (disparity, peak) of the same pair computed as one frame; the gathered rasters must equal
+    it bit for bit.  Runs on every rank; returns the report on rank 0."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import partition
+    nd = 2 * D + 1
+    left_h, right_h = synth_pair(H, W, D, seed)
+    r0, n = partition.row_strips(H, world)[rank]
+    lo, nin = partition.strip_input_rows(r0, n, H, args.window)
+    left = torch.from_numpy(np.ascontiguousarray(left_h[lo:lo + nin])).to(dev)
+    right = torch.from_numpy(np.ascontiguousarray(right_h[lo:lo + nin])).to(dev)
+    del left_h, right_h
+
+    def lib_waits_for_torch():
+        stream.wait_stream(torch.cuda.current_stream())
+
+    def torch_waits_for_lib():
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        torch.cuda.current_stream().wait_event(ev)
+
+    def compute(disp_t, peak_t, local_row0, nrows):
+        with torch.cuda.stream(stream):
+            ctx.bind_pair_torch(left, right)                 # every step rebuilds the strip's tables
+            ctx.ncc_dense_torch(args.window, -D, D, disp_t, peak_t, row0=local_row0, nrows=nrows)
+
+    job = StripJob(rank, world, H, W, args.window, dev, compute, lib_waits_for_torch, torch_waits_for_lib, nbuf=2, gather=True)
+
+    def drain():
+        job.drain()
+        stream.synchronize()
+        torch.cuda.synchronize()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        job.step(i)
+    drain()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        job.step(i)
+    drain()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        return None
+    gd, gp = job.result(max(args.steps - 1, 0))
+    same = bool(torch.equal(gd.view(torch.int32), full_frame[0].view(torch.int32))
+                and torch.equal(gp.view(torch.int32), full_frame[1].view(torch.int32)))
+    return {"partition": "strips", "scaling": "strong", "n_gpus": world, "steps": args.steps,
+            "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4),
+            "value": round(float(H) * W * nd * args.steps / dt / 1e9, 3), "unit": "Gpx*disp/s",
+            "rows_per_rank": [n_ for _, n_ in partition.row_strips(H, world)],
+            "halo_rows": args.window // 2, "gathered_equals_full_frame_bits": same,
+            "note": "rank 0's pair of the timed run, ONE pair sharded by row strips (each rank holds its strip plus halo rows only), "
+                    "rows gathered into rank 0's rasters as grouped point-to-point transfers overlapped with the next step"}
 
 
 def synth_pair(H, W, D, seed):
@@ -667,10 +743,44 @@ def main():
         if world == 1 and args.extras == "on":
             result["path_f"] = bench_path_f(ctx, stream, dev, left_h, cpu=args.cpu_rows > 0)
             result["ncc16"] = bench_ncc16(ctx, stream, dev, cpu=args.cpu_rows > 0)
-        print(json.dumps(result), flush=True)
+    # The other partition on the same ranks (outside the timed region above).  It needs every rank; a rank that
+    # failed or hangs in it must not cost the line above: a watchdog prints the line without this leg and ends the
+    # process when the leg (or the final barrier) does not come back.
+    import threading
+    printed = [False]
+
+    def emit():
+        if rank == 0 and not printed[0]:
+            printed[0] = True
+            print(json.dumps(result), flush=True)
+
+    def give_up():
+        if rank == 0 and not printed[0]:
+            result["strips"] = {"error": "did not finish within %d s" % STRIPS_LEG_LIMIT_S}
+        emit()
+        os._exit(0)
+
+    want_leg = (not strips_mode) and args.gpus == world and (
+        (world > 1 and args.strips_leg == "on" and args.gather == "on") or args.strips_leg == "force")
+    dog = None
+    if want_leg or world > 1:
+        dog = threading.Timer(STRIPS_LEG_LIMIT_S, give_up)
+        dog.daemon = True
+        dog.start()
+    if want_leg:
+        try:
+            leg = strips_leg(args, rank, world, dev, ctx, stream, H, W, D, 0xC0FFEE + 2,
+                             last_result(args.steps) if rank == 0 else None)
+        except Exception as e:      # reported, never fatal for the measured line
+            leg = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            result["strips"] = leg
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if dog:
+        dog.cancel()
     ctx.close()
 
 
