@@ -4,7 +4,9 @@
 // read is what a GDAL-reading host would do as well.
 //
 //   image3_mi left.pgm right.pgm [--xyz out.xyz] [--dispersion d.tif] [--min-size 32]
-//             [--dense window dmin dmax disp.tif]
+//             [--dense window dmin dmax disp.tif] [--devices 0,1,...]
+// --devices: the recursion's tile batches and the dense correlation's row strips are shared out over
+// the listed GPUs (mis_create_group); the outputs are the same files.
 // Cameras are read from <left>.yaml and <right>.yaml (image3.cpp:1014-1023) when --xyz is given.
 #include <cstdio>
 #include <cstdlib>
@@ -59,15 +61,22 @@ int main(int argc, char** argv)
     const char *xyz_name = nullptr, *disp_name = nullptr, *dense_name = nullptr;
     int min_size = 32, window = 0, dmin = 0, dmax = 0;     // minSize default of image3.cpp:73
     std::vector<const char*> files;
+    std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--xyz") && i + 1 < argc) xyz_name = argv[++i];
         else if (!strcmp(argv[i], "--dispersion") && i + 1 < argc) disp_name = argv[++i];
         else if (!strcmp(argv[i], "--min-size") && i + 1 < argc) min_size = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--dense") && i + 4 < argc) {
             window = atoi(argv[++i]); dmin = atoi(argv[++i]); dmax = atoi(argv[++i]); dense_name = argv[++i];
+        } else if (!strcmp(argv[i], "--devices") && i + 1 < argc) {
+            for (const char* p = argv[++i]; *p;) {
+                devices.push_back(atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
         } else files.push_back(argv[i]);
     }
-    if (files.size() != 2) die("usage: image3_mi left.pgm right.pgm [--xyz f] [--dispersion f] [--min-size n] [--dense w dmin dmax f]");
+    if (files.size() != 2) die("usage: image3_mi left.pgm right.pgm [--xyz f] [--dispersion f] [--min-size n] [--dense w dmin dmax f] [--devices 0,1,...]");
 
     std::vector<unsigned char> a, b;
     int w = 0, h = 0, w2 = 0, h2 = 0, t1 = 0, t2 = 0;
@@ -75,14 +84,22 @@ int main(int argc, char** argv)
     printf("Got image %d x %d x 1\nGot image %d x %d x 1\n", w, h, w2, h2);
     if (w != w2 || h != h2 || t1 != t2) die("Source dataset geometries should match");
 
+    const size_t stride = (size_t)w * (t1 == MIS_U8 ? 1 : 2);
     mis_ctx* ctx = nullptr;
-    if (mis_create(0, &ctx)) die(mis_last_error(nullptr));
-    if (mis_upload_pair(ctx, a.data(), b.data(), t1, w, h, (size_t)w * (t1 == MIS_U8 ? 1 : 2))) die("upload", ctx);
+    mis_group* grp = nullptr;
+    if (mis_create(devices.empty() ? 0 : devices[0], &ctx)) die(mis_last_error(nullptr));
+    if (!devices.empty() && mis_create_group(devices.data(), (int)devices.size(), &grp)) die(mis_group_last_error(nullptr));
 
     // calcDisparityMap(bbox1, bbox2), image3.cpp:1032
     std::vector<mis_leaf> leaves(1 << 20);
     int n = 0, evaluated = 0;
-    if (mis_disparity_map(ctx, w, h, min_size, leaves.data(), (int)leaves.size(), &n, &evaluated)) die("disparity map", ctx);
+    if (grp) {
+        if (mis_group_upload_pair(grp, a.data(), b.data(), t1, w, h, stride)) die(mis_group_last_error(grp));
+        if (mis_group_disparity_map(grp, w, h, min_size, leaves.data(), (int)leaves.size(), &n, &evaluated)) die(mis_group_last_error(grp));
+    } else {
+        if (mis_upload_pair(ctx, a.data(), b.data(), t1, w, h, stride)) die("upload", ctx);
+        if (mis_disparity_map(ctx, w, h, min_size, leaves.data(), (int)leaves.size(), &n, &evaluated)) die("disparity map", ctx);
+    }
     if (n > (int)leaves.size()) die("too many leaves");
     printf("%d tiles correlated, %d leaves\n", evaluated, n);
 
@@ -108,9 +125,13 @@ int main(int argc, char** argv)
     }
     if (dense_name) {                                            // the dense mode image3.cpp:866-870 asks for
         std::vector<float> out(2 * (size_t)w * h);
-        if (mis_ncc_dense(ctx, window, dmin, dmax, out.data(), out.data() + (size_t)w * h, nullptr, nullptr)) die("dense NCC", ctx);
+        if (grp) {
+            if (mis_group_ncc_dense(grp, a.data(), b.data(), t1, w, h, stride, window, dmin, dmax,
+                                    out.data(), out.data() + (size_t)w * h, nullptr, nullptr)) die(mis_group_last_error(grp));
+        } else if (mis_ncc_dense(ctx, window, dmin, dmax, out.data(), out.data() + (size_t)w * h, nullptr, nullptr)) die("dense NCC", ctx);
         if (mis_write_tiff_f32(dense_name, out.data(), w, h, 2)) die("could not write the dense disparity raster");
     }
+    mis_destroy_group(grp);
     mis_destroy(ctx);
     return 0;
 }

@@ -132,3 +132,11 @@ def test_cpp_host_program_on_the_c_abi(ctx, tmp_path):
     got = np.frombuffer(raw, np.float32, 2 * 256 * 256, 8).reshape(2, 256, 256)
     assert np.array_equal(got[0].view(np.uint32), dense["disp"].view(np.uint32))
     assert np.array_equal(got[1].view(np.uint32), dense["peak"].view(np.uint32))
+    # --devices: the same files through a group of GPUs (every slot is GPU 0 here)
+    paths2 = [os.path.join(tmp_path, n) for n in ("o2.xyz", "d2.tif", "n2.tif")]
+    r2 = subprocess.run([exe, left, right, "--xyz", paths2[0], "--dispersion", paths2[1], "--min-size", "32",
+                         "--dense", "11", "-20", "20", paths2[2], "--devices", "0,0,0"], capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 0, r2.stderr
+    assert r2.stdout == r.stdout
+    for p1, p2 in zip((xyz_path, tif_path, dense_path), paths2):
+        assert open(p1, "rb").read() == open(p2, "rb").read()
