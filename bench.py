@@ -208,7 +208,18 @@ class StripJob:
         return self.out[i % self.nbuf]
 
 
-def strips_leg(args, rank, world, dev, ctx, stream, H, W, D, seed, full_frame):
+def bench_cameras(W, H):
+    """Two synthetic nadir cameras (f = 10000 px, height 3000 m, baseline 900 m, R = I); the second principal point
+    carries the f B / H = 3000 px between the origins of the two crops."""
+    import numpy as np
+    import mistereo
+    A = [[10000.0, 0.0, W / 2.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
+    A2 = [[10000.0, 0.0, W / 2.0 + 10000.0 * 900.0 / 3000.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
+    return (mistereo.make_camera(A, np.eye(3), [0.0, 0.0, -3000.0]),
+            mistereo.make_camera(A2, np.eye(3), [-900.0, 0.0, -3000.0]))
+
+
+def strips_leg(args, rank, world, dev, ctx, stream, H, W, D, seed, full_frame, full_frame_matched):
     """The strips partition timed on the ranks of a frames-partition run: the pair of `seed` (rank 0's) sharded by
     row strips with halo, every rank holding only its strip, rows sent to rank 0 as grouped point-to-point transfers.
     full_frame: rank 0's (disparity, peak) of the same pair computed as one frame; the gathered rasters must equal
@@ -264,6 +275,27 @@ def strips_leg(args, rank, world, dev, ctx, stream, H, W, D, seed, full_frame):
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # every rank triangulates the rows it computed, where they are (raster row k is frame row k + its first input row):
+    # the XYZ work is sharded like the correlation; the matched counts add up to the whole frame's
+    cam1, cam2 = bench_cameras(W, H)
+    own_d, own_p = job.out[max(args.steps - 1, 0) % job.nbuf]
+    xyz = torch.empty((own_d.shape[0], W, 3), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        t_tri = time.perf_counter()
+        cnt = ctx.triangulate_disparity_rows_torch(cam1, cam2, own_d, own_p, 0.75, xyz, job.local_row0, job.n,
+                                                   0 if rank == 0 else job.lo) if job.n > 0 else 0
+        stream.synchronize()
+        t_tri = time.perf_counter() - t_tri
+    del xyz
+    tot = torch.tensor([float(cnt), t_tri], dtype=torch.float64, device=dev)
+    if world > 1:
+        tsum = tot.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tot, op=dist.ReduceOp.MAX)
+        cnt_all, t_tri = int(tsum[0].item()), float(tot[1].item())
+    else:
+        cnt_all = int(cnt)
     if rank != 0:
         return None
     gd, gp = job.result(max(args.steps - 1, 0))
@@ -274,6 +306,8 @@ def strips_leg(args, rank, world, dev, ctx, stream, H, W, D, seed, full_frame):
             "value": round(float(H) * W * nd * args.steps / dt / 1e9, 3), "unit": "Gpx*disp/s",
             "rows_per_rank": [n_ for _, n_ in partition.row_strips(H, world)],
             "halo_rows": args.window // 2, "gathered_equals_full_frame_bits": same,
+            "matched_points_all_ranks": cnt_all, "matched_points_equal_full_frame": bool(cnt_all == full_frame_matched),
+            "triangulation_ms_per_rank_strip": round(t_tri * 1e3, 3),
             "note": "rank 0's pair of the timed run, ONE pair sharded by row strips (each rank holds its strip plus halo rows only), "
                     "rows gathered into rank 0's rasters as grouped point-to-point transfers overlapped with the next step"}
 
@@ -622,11 +656,9 @@ def main():
         # baseline 900 m, R = I), timed on its own, outside the timed region.  The second camera's principal point
         # carries the f B / H = 3000 px between the origins of the two crops, so that the pair's disparities of
         # +-200 px are +-200 m of relief around z = 0 (a crop pair whose disparities straddle zero has such an offset).
-        A = [[10000.0, 0.0, W / 2.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
-        A2 = [[10000.0, 0.0, W / 2.0 + 10000.0 * 900.0 / 3000.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]]
-        cam1 = mistereo.make_camera(A, np.eye(3), [0.0, 0.0, -3000.0])
-        cam2 = mistereo.make_camera(A2, np.eye(3), [-900.0, 0.0, -3000.0])
-        cam2_same_pp = mistereo.make_camera(A, np.eye(3), [-900.0, 0.0, -3000.0])
+        cam1, cam2 = bench_cameras(W, H)
+        cam2_same_pp = mistereo.make_camera([[10000.0, 0.0, W / 2.0], [0.0, 10000.0, H / 2.0], [0.0, 0.0, 1.0]], np.eye(3),
+                                            [-900.0, 0.0, -3000.0])
         xyz = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
         n_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
@@ -770,7 +802,7 @@ def main():
     if want_leg:
         try:
             leg = strips_leg(args, rank, world, dev, ctx, stream, H, W, D, 0xC0FFEE + 2,
-                             last_result(args.steps) if rank == 0 else None)
+                             last_result(args.steps) if rank == 0 else None, matched if rank == 0 else None)
         except Exception as e:      # reported, never fatal for the measured line
             leg = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:

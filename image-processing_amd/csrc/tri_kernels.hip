@@ -298,11 +298,14 @@ __global__ __launch_bounds__(256) void tri_points_kernel(TriCam c1, TriCam c2, b
 __global__ __launch_bounds__(256) void tri_disparity_kernel(TriCam c1, TriCam c2, bool cams_fast,
                                                             const float* __restrict__ disp,
                                                             const float* __restrict__ peak, float min_peak,
-                                                            bool subpixel, int W, int H, float* __restrict__ xyz,
+                                                            bool subpixel, int W, int row0, int frame_row0,
+                                                            float* __restrict__ xyz,
                                                             unsigned long long* __restrict__ count)
 {
+    // grid.y rows starting at row row0 of the rasters; raster row k is row k + frame_row0 of the frame the cameras
+    // describe (a strip of a frame held as a raster of its own)
     int x = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
+    int y = row0 + blockIdx.y;
     bool ok = false;
     float X = NAN, Y = NAN, Z = NAN;
     if (x < W) {
@@ -313,7 +316,8 @@ __global__ __launch_bounds__(256) void tri_disparity_kernel(TriCam c1, TriCam c2
             // the reference hands integer pixels to calculateXYZ (image3.cpp:812-824): the disparity is rounded;
             // subpixel: the fractional column x - d goes into the same arithmetic
             const float u2 = subpixel ? (float)x - d : (float)(x - (int)rintf(d));
-            triangulate_point(c1, c2, cams_fast, (float)x, (float)y, u2, (float)y, X, Y, Z);
+            const float v = (float)(y + frame_row0);
+            triangulate_point(c1, c2, cams_fast, (float)x, v, u2, v, X, Y, Z);
         }
         xyz[3 * o] = X; xyz[3 * o + 1] = Y; xyz[3 * o + 2] = Z;
     }
@@ -421,8 +425,22 @@ int mis_triangulate_disparity_ex_device(mis_ctx* ctx, const mis_camera* c1, cons
     int rc = tri_check(ctx, c1, c2);
     if (rc) return rc;
     if (!ctx->img[0]) return mis_fail(ctx, MIS_ERR_STATE, "triangulate: no image pair bound (raster size unknown)");
+    return mis_triangulate_disparity_rows_device(ctx, c1, c2, d_disp, d_peak, min_peak, flags, ctx->width, 0, ctx->height, 0,
+                                                 d_xyz, n_matched);
+}
+
+int mis_triangulate_disparity_rows_device(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                                          const float* d_disp, const float* d_peak, float min_peak, int flags,
+                                          int width, int row0, int nrows, int frame_row0,
+                                          float* d_xyz, long long* n_matched)
+{
+    int rc = tri_check(ctx, c1, c2);
+    if (rc) return rc;
     if (!d_disp || !d_peak || !d_xyz) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: NULL buffer");
     if (flags & ~MIS_TRI_SUBPIXEL) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: unknown flags 0x%x", flags);
+    if (width <= 0 || row0 < 0 || nrows < 0 || nrows > 65535 || (long long)row0 + nrows > 0x7FFFFFFF)
+        return mis_fail(ctx, MIS_ERR_ARG, "triangulate: rows [%d,%d) of a raster %d wide", row0, row0 + nrows, width);
+    if (nrows == 0) { if (n_matched) *n_matched = 0; return MIS_OK; }
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t cnt_bytes = (size_t)TRI_COUNT_SLOTS * 128;
     rc = mis_reserve(ctx, &ctx->tri_buf, &ctx->tri_bytes, cnt_bytes);
@@ -430,9 +448,9 @@ int mis_triangulate_disparity_ex_device(mis_ctx* ctx, const mis_camera* c1, cons
     unsigned long long* cnt = (unsigned long long*)ctx->tri_buf;
     MIS_HIP(ctx, hipMemsetAsync(cnt, 0, cnt_bytes, ctx->stream));
     TriCam a = make_cam(c1), b = make_cam(c2);
-    const int W = ctx->width, H = ctx->height;
-    hipLaunchKernelGGL(tri_disparity_kernel, dim3((W + 255) / 256, H), dim3(256), 0, ctx->stream, a, b,
-                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, (flags & MIS_TRI_SUBPIXEL) != 0, W, H, d_xyz, cnt);
+    hipLaunchKernelGGL(tri_disparity_kernel, dim3((width + 255) / 256, nrows), dim3(256), 0, ctx->stream, a, b,
+                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, (flags & MIS_TRI_SUBPIXEL) != 0, width, row0, frame_row0,
+                       d_xyz, cnt);
     MIS_HIP(ctx, hipGetLastError());
     if (n_matched) {
         unsigned long long h[TRI_COUNT_SLOTS * 16];
@@ -465,7 +483,7 @@ int mis_triangulate_disparity_noalloc(mis_ctx* ctx, const mis_camera* c1, const 
     MIS_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)TRI_COUNT_SLOTS * 128, ctx->stream));
     TriCam a = make_cam(c1), b = make_cam(c2);
     hipLaunchKernelGGL(tri_disparity_kernel, dim3((width + 255) / 256, height), dim3(256), 0, ctx->stream, a, b,
-                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, false, width, height, d_xyz, cnt);
+                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, false, width, 0, 0, d_xyz, cnt);
     if (d_n_matched)
         hipLaunchKernelGGL(tri_count_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt, d_n_matched);
     MIS_HIP(ctx, hipGetLastError());

@@ -55,7 +55,7 @@ EXPORTS = [
     "mis_triangulate", "mis_triangulate_device", "mis_triangulate_disparity_device",
     "mis_triangulate_disparity_noalloc", "mis_triangulate_disparity_ex_device", "mis_ncc_dense_rows",
     "mis_create_group", "mis_destroy_group", "mis_group_size", "mis_group_last_error", "mis_group_ncc_dense",
-    "mis_group_upload_pair", "mis_group_xcorr_tiles", "mis_group_disparity_map",
+    "mis_group_upload_pair", "mis_group_xcorr_tiles", "mis_group_disparity_map", "mis_triangulate_disparity_rows_device",
     "mis_disparity_map", "mis_write_xyz", "mis_write_xyz_ex", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
     "mis_set_extra_bands_device", "mis_upload_extra_bands", "mis_masked_peak",
     "mis_profile_enable", "mis_profile_read", "mis_version",
@@ -118,6 +118,7 @@ def load_library():
         lib.mis_profile_read.argtypes = [vp, vp, vp, vp, vp]
         lib.mis_triangulate_disparity_device.argtypes = [vp, vp, vp, vp, vp, f32, vp, vp]
         lib.mis_triangulate_disparity_ex_device.argtypes = [vp, vp, vp, vp, vp, f32, i32, vp, vp]
+        lib.mis_triangulate_disparity_rows_device.argtypes = [vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, vp, vp]
         lib.mis_triangulate_disparity_noalloc.argtypes = [vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]
         _lib = lib
     return _lib
@@ -520,6 +521,16 @@ class Context:
             self._check(self._lib.mis_triangulate_disparity_device(self._h, C.byref(cam1), C.byref(cam2), _dev_ptr(disp),
                                                                    _dev_ptr(peak), C.c_float(min_peak), _dev_ptr(xyz),
                                                                    C.byref(n) if count else None))
+        return n.value if count else None
+
+    def triangulate_disparity_rows_torch(self, cam1, cam2, disp, peak, min_peak, xyz, row0, nrows, frame_row0,
+                                         count=True, subpixel=False):
+        """Rows [row0, row0+nrows) of rasters that are a strip of a frame: raster row k is frame row k + frame_row0."""
+        n = C.c_longlong(0)
+        self._check(self._lib.mis_triangulate_disparity_rows_device(
+            self._h, C.byref(cam1), C.byref(cam2), _dev_ptr(disp), _dev_ptr(peak), C.c_float(min_peak),
+            TRI_SUBPIXEL if subpixel else 0, disp.shape[1], row0, nrows, frame_row0, _dev_ptr(xyz),
+            C.byref(n) if count else None))
         return n.value if count else None
 
     def triangulate_disparity_noalloc_torch(self, cam1, cam2, disp, peak, min_peak, xyz, n_matched=None):

@@ -207,6 +207,15 @@ int mis_triangulate_disparity_ex_device(mis_ctx* ctx, const mis_camera* c1, cons
                                         const float* d_disp, const float* d_peak, float min_peak, int flags,
                                         float* d_xyz, long long* n_matched);
 
+/* The same for rows of a frame that are held as a raster of their own (a strip of a frame split over GPUs):
+ * triangulates rows [row0, row0+nrows) of d_disp / d_peak (rasters `width` wide, no pair needs to be bound), whose
+ * row k is row k + frame_row0 of the frame the cameras describe, into the same rows of d_xyz (3 floats per pixel).
+ * A strip triangulated this way equals the same rows of the whole frame's result bit for bit.  nrows <= 65535. */
+int mis_triangulate_disparity_rows_device(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
+                                          const float* d_disp, const float* d_peak, float min_peak, int flags,
+                                          int width, int row0, int nrows, int frame_row0,
+                                          float* d_xyz, long long* n_matched);
+
 /* No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same computation as
  * mis_triangulate_disparity_device, but the raster size is passed in (no pair needs to be bound), the

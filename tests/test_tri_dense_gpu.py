@@ -148,6 +148,43 @@ def test_subpixel_columns_to_xyz(ctx):
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+def test_strips_of_a_frame_triangulated_on_their_own(ctx):
+    """A frame split into row strips (several GPUs): every strip held as a raster of its own and triangulated with
+    its frame row offset gives the rows of the whole frame's result bit for bit, counts included; rounded and
+    subpixel columns."""
+    import torch
+    h, w = 96, 700
+    rng = np.random.default_rng(17)
+    disp = (rng.integers(-150, 151, (h, w)) + rng.random((h, w)) - 0.5).astype(np.float32)
+    peak = rng.random((h, w)).astype(np.float32)
+    disp[rng.random((h, w)) < 0.05] = np.float32(mistereo.INVALID_DISP)
+    c1, c2 = _cameras(w, h, 900.0)
+    cam1, cam2 = mistereo.make_camera(*c1), mistereo.make_camera(*c2)
+    ctx.upload_pair(np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8))     # the whole-frame entry takes its size from the pair
+    td, tp = torch.from_numpy(disp).cuda(), torch.from_numpy(peak).cuda()
+    for subpixel in (False, True):
+        full = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        nfull = ctx.triangulate_disparity_torch(cam1, cam2, td, tp, MIN_PEAK, full, subpixel=subpixel)
+        ctx.synchronize()
+        total = 0
+        for r0, n in ((0, 31), (31, 1), (32, 40), (72, 24)):
+            sd, sp = td[r0:r0 + n].contiguous(), tp[r0:r0 + n].contiguous()      # the strip as a raster of its own
+            sx = torch.full((n, w, 3), 5.0, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            total += ctx.triangulate_disparity_rows_torch(cam1, cam2, sd, sp, MIN_PEAK, sx, 0, n, r0, subpixel=subpixel)
+            ctx.synchronize()
+            assert torch.equal(sx.view(torch.int32), full[r0:r0 + n].view(torch.int32))
+        assert total == nfull
+        # a window of rows inside a larger raster: the other rows are left alone
+        part = torch.full((h, w, 3), 5.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.triangulate_disparity_rows_torch(cam1, cam2, td, tp, MIN_PEAK, part, 10, 20, 0, subpixel=subpixel)
+        ctx.synchronize()
+        assert torch.equal(part[10:30].view(torch.int32), full[10:30].view(torch.int32))
+        assert bool((part[:10] == 5).all()) and bool((part[30:] == 5).all())
+
+
 def test_thresholds_and_empty_result(ctx):
     """min_peak above every peak: nothing matched, all NaN, count 0; min_peak below every peak: every
     valid pixel matched (including zero-disparity pixels, whose rays never meet: inf / NaN from the
