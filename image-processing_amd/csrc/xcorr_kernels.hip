@@ -561,7 +561,20 @@ __global__ __launch_bounds__(512) void xc_cols(int w, int h, int logw, int logh,
         if (ep != e) A[xp<PAD>(ep)] = make_float2(re, -im);
     }
     __syncthreads();
-    fft_dit_inv<512, PAD>(A, logh, 2 * CB, stw);
+    if (g != 0) {
+        // The correlation is real, so its spectrum is Hermitian, P[-ky,-kx] = conj(P[ky,kx]), and the inverse column
+        // transform of a column -kx is the conjugate of column kx's, row by row: only the first block is
+        // transformed, the partner block (column j <-> CB-1-j) is written as its conjugate.
+        fft_dit_inv<512, PAD>(A, logh, CB, stw);
+        for (int i = threadIdx.x; i < CB * h; i += 512) {
+            const int r = i >> logcb, c = i & (CB - 1);
+            const float2 v = A[xp<PAD>(c * h + r)];
+            sa[(size_t)r * w + c0q[0] + c] = v;
+            sa[(size_t)r * w + c0q[1] + (CB - 1 - c)] = make_float2(v.x, -v.y);
+        }
+        return;
+    }
+    fft_dit_inv<512, PAD>(A, logh, 2 * CB, stw);      // the two self-paired blocks
     for (int i = threadIdx.x; i < 2 * CB * h; i += 512) {
         const int q = i >= nB ? 1 : 0, ii = i - q * nB;
         const int r = ii >> logcb, c = ii & (CB - 1);
