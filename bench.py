@@ -16,6 +16,8 @@ In both, disparity and peak rasters are gathered to rank 0 over RCCL while the n
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--partition frames|strips]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Both forms work for N > 1: without a launcher's environment (no WORLD_SIZE) the first form starts the second as a
+child process before it touches the GPU, relays the ranks' output and returns their worst exit status.
 
 Prints ONE JSON line on rank 0.  At N=1 the line also carries, outside the headline value, the
 FFT tile correlation (path_f) and the 16-bit dense NCC (ncc16) with their own rooflines and CPU
@@ -57,7 +59,105 @@ def parse(argv=None):
                          "same ranks (reported under \"strips\"); force: run that leg at N=1 too (one strip, no transfers)")
     ap.add_argument("--second-peak", choices=["on", "off"], default="on",
                     help="at N=1 with extras: also time the step with the second-peak output (off for counter passes that sum per step)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="test only: no GPU and no library call -- the rank processes rendezvous over gloo and run the step loops of "
+                         "both partitions with a stand-in for the correlation, to check the launcher, the gathers and the line's shape")
     return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` (N > 1) started without a launcher's environment: start the N rank processes ourselves,
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD of this process, which has made no
+    GPU call (torch is not even imported here), relay what the ranks print, and return the launcher's exit status
+    (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1" if args.rehearse else str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def rehearse(args, rank, world):
+    """--rehearse: the rank processes of a multi-rank run without a GPU.  The same StripJob / GatherPipeline objects
+    and the same loop order as the measured run, over gloo on CPU tensors, with a stand-in for the library call that
+    writes values made of (rank, step, global row); rank 0 checks what it gathered and prints a line of the measured
+    line's shape whose value is null.  Nothing here is a measurement."""
+    import torch
+    import torch.distributed as dist
+    import partition
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    H = W = min(args.size, 96)
+    nbuf = 2
+    packed = [torch.zeros((2, H, W)) for _ in range(nbuf)]
+    pipe = GatherPipeline(rank, world, packed) if world > 1 else None
+    t0 = time.perf_counter()
+    for i in range(args.warmup + args.steps):
+        b = i % nbuf
+        if pipe:
+            pipe.reuse(b)
+        packed[b][0].fill_(1000.0 * i + rank)
+        packed[b][1].fill_(-1000.0 * i - rank)
+        if pipe:
+            pipe.submit(b)
+    if pipe:
+        pipe.drain()
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    last = args.warmup + args.steps - 1
+    frames_ok = True
+    if pipe and rank == 0 and last >= 0:
+        for r in range(world):
+            g = pipe.gathered[last % nbuf][r]
+            frames_ok = frames_ok and bool((g[0] == 1000.0 * last + r).all()) and bool((g[1] == -1000.0 * last - r).all())
+    # the strips partition on the same ranks
+    state = {"step": 0}
+    box = []
+
+    def compute(disp, peak, local_row0, nrows):
+        rows = torch.arange(box[0].r0, box[0].r0 + nrows, dtype=torch.float32)[:, None]
+        disp[local_row0:local_row0 + nrows] = rows * 10 + state["step"]
+        peak[local_row0:local_row0 + nrows] = -rows - 1000 * state["step"]
+
+    job = StripJob(rank, world, H, W, args.window, "cpu", compute, gather=world > 1)
+    box.append(job)
+    for i in range(args.warmup + args.steps):
+        state["step"] = i
+        job.step(i)
+    job.drain()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        rows = torch.arange(H, dtype=torch.float32)[:, None].expand(H, W)
+        d, p = job.result(max(last, 0))
+        strips_ok = bool(torch.equal(d, rows * 10 + max(last, 0))) and bool(torch.equal(p, -rows - 1000 * max(last, 0)))
+        print(json.dumps({
+            "metric": "NCC throughput", "value": None, "unit": "Gpx*disp/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "none: --rehearse runs no correlation (launcher, rendezvous and gathers only, gloo on the CPU)",
+            "rehearsal": True, "config": {"workload": "rehearsal %dx%d" % (W, H), "partition": "frames", "gather_to_rank0": world > 1},
+            "frames_gather_ok": frames_ok, "wall_s": round(dt, 3),
+            "strips": {"partition": "strips", "scaling": "strong", "n_gpus": world,
+                       "rows_per_rank": [n_ for _, n_ in partition.row_strips(H, world)], "halo_rows": args.window // 2,
+                       "gathered_equals_full_frame_bits": strips_ok}}), flush=True)
+        ok = frames_ok and strips_ok
+    else:
+        ok = True
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 STRIPS_LEG_LIMIT_S = 150      # the strips leg and the final barrier of a multi-rank run must come back within this
@@ -520,6 +620,18 @@ def bench_ncc16(ctx, stream, dev, steps=3, cpu=True):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become the launcher (before torch is imported or any GPU call is made)
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if args.rehearse:
+        sys.exit(rehearse(args, rank, world))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -527,14 +639,6 @@ def main():
     import mistereo
     import partition
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
-                  file=sys.stderr)
-        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr)
         sys.exit(2)
@@ -779,18 +883,25 @@ def main():
     # failed or hangs in it must not cost the line above: a watchdog prints the line without this leg and ends the
     # process when the leg (or the final barrier) does not come back.
     import threading
+    lock = threading.Lock()
     printed = [False]
+    headline = json.dumps(result) if rank == 0 else None      # the line as it stands before the leg: what the watchdog prints
 
-    def emit():
-        if rank == 0 and not printed[0]:
-            printed[0] = True
-            print(json.dumps(result), flush=True)
+    def emit(line):
+        with lock:
+            if rank == 0 and not printed[0]:
+                printed[0] = True
+                print(line, flush=True)
 
     def give_up():
-        if rank == 0 and not printed[0]:
-            result["strips"] = {"error": "did not finish within %d s" % STRIPS_LEG_LIMIT_S}
-        emit()
-        os._exit(0)
+        # the leg or the final barrier hangs: the measured line is still printed (without the leg), but the run FAILS
+        if rank == 0:
+            late = json.loads(headline)
+            late["strips"] = {"error": "did not finish within %d s" % STRIPS_LEG_LIMIT_S}
+            emit(json.dumps(late))
+        print("bench.py: rank %d gave up waiting for the strips leg or the final barrier after %d s" % (rank, STRIPS_LEG_LIMIT_S),
+              file=sys.stderr, flush=True)
+        os._exit(3)
 
     want_leg = (not strips_mode) and args.gpus == world and (
         (world > 1 and args.strips_leg == "on" and args.gather == "on") or args.strips_leg == "force")
@@ -807,7 +918,7 @@ def main():
             leg = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
             result["strips"] = leg
-    emit()
+    emit(json.dumps(result) if rank == 0 else None)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

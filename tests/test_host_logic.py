@@ -297,3 +297,27 @@ def test_tiff_writer_band_interleaved_float32(tmp_path):
     one = os.path.join(tmp_path, "one.tif")
     mistereo.write_tiff_f32(one, planes[0])
     assert np.array_equal(np.asarray(Image.open(one)), planes[0])
+
+
+def test_bench_starts_its_own_rank_processes():
+    """`python bench.py --gpus 2` without a launcher's environment starts the two rank processes itself (a child
+    torch.distributed.run), relays rank 0's line and returns the ranks' exit status.  --rehearse keeps the GPU out of
+    it: gloo, CPU tensors, a stand-in for the library call, the measured run's own gather objects."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["rehearsal"] is True and line["value"] is None
+    assert line["frames_gather_ok"] is True
+    assert line["strips"]["n_gpus"] == 2 and line["strips"]["gathered_equals_full_frame_bits"] is True
+    assert sum(line["strips"]["rows_per_rank"]) == 96
+    # a launcher's environment that disagrees with --gpus is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env2, timeout=120)
+    assert p.returncode == 2
