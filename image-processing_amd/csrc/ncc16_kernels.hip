@@ -550,6 +550,7 @@ static int ncc16_prepare(mis_ctx* ctx, int window, int need_lo, int need_hi)
         w->built_lo = need_lo; w->built_hi = need_hi;
     }
     w->pitch = pitch; w->rows = H;
+    w->pair_serial = 0;               // the cache claims nothing until every launch below has been accepted
     hipStream_t s = ctx->stream;
     const size_t stride_px = ctx->stride / 2;
     const dim3 block(256);

@@ -1096,6 +1096,7 @@ static int ncc_prepare(mis_ctx* ctx, int window, bool use_side, int need_lo, int
     }
     w->building = true;
     w->pitch = pitch; w->rows = H;
+    w->pair_serial = 0;               // the cache claims nothing until every launch below has been accepted
     dim3 block(256);
     hipStream_t s = ctx->stream, sv = ctx->stream;       // sv: side stream when there is one
     if (use_side) {

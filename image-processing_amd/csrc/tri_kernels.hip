@@ -350,6 +350,7 @@ __global__ __launch_bounds__(64) void tri_count_sum_kernel(const unsigned long l
 // mis_tri_init_device for the device they run on.
 static __device__ __align__(256) unsigned long long scratch[TRI_COUNT_SLOTS * 16];
 #define TRI_MAX_DEVICES 64
+#define TRI_MAX_GRID_ROWS 65535
 static unsigned long long* g_tri_scratch[TRI_MAX_DEVICES];      // per device, filled by mis_tri_init_device
 static std::mutex g_tri_mu;
 
@@ -438,8 +439,9 @@ int mis_triangulate_disparity_rows_device(mis_ctx* ctx, const mis_camera* c1, co
     if (rc) return rc;
     if (!d_disp || !d_peak || !d_xyz) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: NULL buffer");
     if (flags & ~MIS_TRI_SUBPIXEL) return mis_fail(ctx, MIS_ERR_ARG, "triangulate: unknown flags 0x%x", flags);
-    if (width <= 0 || row0 < 0 || nrows < 0 || nrows > 65535 || (long long)row0 + nrows > 0x7FFFFFFF)
-        return mis_fail(ctx, MIS_ERR_ARG, "triangulate: rows [%d,%d) of a raster %d wide", row0, row0 + nrows, width);
+    if (width <= 0 || row0 < 0 || nrows < 0 || frame_row0 < 0 || (long long)row0 + nrows + frame_row0 > 0x7FFFFFFF)
+        return mis_fail(ctx, MIS_ERR_ARG, "triangulate: rows [%d,%d) of a raster %d wide, frame row offset %d", row0, row0 + nrows,
+                        width, frame_row0);
     if (nrows == 0) { if (n_matched) *n_matched = 0; return MIS_OK; }
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t cnt_bytes = (size_t)TRI_COUNT_SLOTS * 128;
@@ -448,9 +450,12 @@ int mis_triangulate_disparity_rows_device(mis_ctx* ctx, const mis_camera* c1, co
     unsigned long long* cnt = (unsigned long long*)ctx->tri_buf;
     MIS_HIP(ctx, hipMemsetAsync(cnt, 0, cnt_bytes, ctx->stream));
     TriCam a = make_cam(c1), b = make_cam(c2);
-    hipLaunchKernelGGL(tri_disparity_kernel, dim3((width + 255) / 256, nrows), dim3(256), 0, ctx->stream, a, b,
-                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, (flags & MIS_TRI_SUBPIXEL) != 0, width, row0, frame_row0,
-                       d_xyz, cnt);
+    for (int done = 0; done < nrows; done += TRI_MAX_GRID_ROWS) {      // a launch covers at most 65535 rows (grid.y)
+        const int slab = nrows - done < TRI_MAX_GRID_ROWS ? nrows - done : TRI_MAX_GRID_ROWS;
+        hipLaunchKernelGGL(tri_disparity_kernel, dim3((width + 255) / 256, slab), dim3(256), 0, ctx->stream, a, b,
+                           tri_cams_fast(a, b), d_disp, d_peak, min_peak, (flags & MIS_TRI_SUBPIXEL) != 0, width, row0 + done, frame_row0,
+                           d_xyz, cnt);
+    }
     MIS_HIP(ctx, hipGetLastError());
     if (n_matched) {
         unsigned long long h[TRI_COUNT_SLOTS * 16];
@@ -482,8 +487,11 @@ int mis_triangulate_disparity_noalloc(mis_ctx* ctx, const mis_camera* c1, const 
     // the array keeps the previous call's counts
     MIS_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)TRI_COUNT_SLOTS * 128, ctx->stream));
     TriCam a = make_cam(c1), b = make_cam(c2);
-    hipLaunchKernelGGL(tri_disparity_kernel, dim3((width + 255) / 256, height), dim3(256), 0, ctx->stream, a, b,
-                       tri_cams_fast(a, b), d_disp, d_peak, min_peak, false, width, 0, 0, d_xyz, cnt);
+    for (int done = 0; done < height; done += TRI_MAX_GRID_ROWS) {
+        const int slab = height - done < TRI_MAX_GRID_ROWS ? height - done : TRI_MAX_GRID_ROWS;
+        hipLaunchKernelGGL(tri_disparity_kernel, dim3((width + 255) / 256, slab), dim3(256), 0, ctx->stream, a, b,
+                           tri_cams_fast(a, b), d_disp, d_peak, min_peak, false, width, done, 0, d_xyz, cnt);
+    }
     if (d_n_matched)
         hipLaunchKernelGGL(tri_count_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt, d_n_matched);
     MIS_HIP(ctx, hipGetLastError());

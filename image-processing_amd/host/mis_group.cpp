@@ -18,7 +18,8 @@ struct mis_group {
     std::string err;
 };
 
-static std::string g_group_create_err;
+// message of the last failed mis_create_group on this thread (there is no group to hold it)
+static thread_local std::string g_group_create_err;
 
 static int group_fail(mis_group* g, int code, const char* fmt, ...)
 {
@@ -99,6 +100,7 @@ int mis_group_ncc_dense(mis_group* g, const void* img1, const void* img2, int dt
                         float* disp, float* peak, int16_t* idisp, float* peak2)
 {
     if (!g) return MIS_ERR_ARG;
+    g->err.clear();
     if (!img1 || !img2 || !disp || !peak) return group_fail(g, MIS_ERR_ARG, "group dense NCC: NULL raster");
     if (width <= 0 || height <= 0) return group_fail(g, MIS_ERR_ARG, "group dense NCC: raster %d x %d", width, height);
     if (window < 3 || window > 31 || !(window & 1)) return group_fail(g, MIS_ERR_ARG, "group dense NCC: window %d not odd in 3..31", window);
@@ -130,6 +132,7 @@ int mis_group_upload_pair(mis_group* g, const void* img1, const void* img2, int 
                           int width, int height, size_t row_stride_bytes)
 {
     if (!g) return MIS_ERR_ARG;
+    g->err.clear();
     const int n_dev = (int)g->ctx.size();
     std::vector<int> rcs(n_dev, MIS_OK);
     auto work = [&](int i) { rcs[i] = mis_upload_pair(g->ctx[i], img1, img2, dtype, width, height, row_stride_bytes); };
@@ -143,6 +146,7 @@ int mis_group_xcorr_tiles(mis_group* g, const mis_rect* r1, const mis_rect* r2, 
                           int tile_w, int tile_h, mis_offset* out)
 {
     if (!g) return MIS_ERR_ARG;
+    g->err.clear();
     if (n < 0 || (n > 0 && (!r1 || !r2 || !out))) return group_fail(g, MIS_ERR_ARG, "group tile correlation: bad tile buffers");
     if (n == 0) return MIS_OK;
     // contiguous shares of the batch, the remainder tiles to the first devices; a share of a few tiles is not worth
@@ -165,11 +169,13 @@ int mis_group_disparity_map(mis_group* g, int image_width, int image_height, int
                             mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles)
 {
     if (!g) return MIS_ERR_ARG;
+    g->err.clear();
     try {
         const MisTileEval eval = [g](const mis_rect* r1, const mis_rect* r2, int n, int w, int h, mis_offset* out) {
             return mis_group_xcorr_tiles(g, r1, r2, n, w, h, out);
         };
         const int rc = mis_disparity_map_with(eval, image_width, image_height, min_size, leaves, max_leaves, n_leaves, n_tiles);
+        // a failed tile batch left its own message (the evaluator's); anything else comes from the driver's checks
         if (rc && g->err.empty()) group_fail(g, rc, rc == MIS_ERR_STATE ? "group disparity map: no overlap" : "group disparity map: bad argument");
         return rc;
     } catch (...) {

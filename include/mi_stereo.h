@@ -210,7 +210,7 @@ int mis_triangulate_disparity_ex_device(mis_ctx* ctx, const mis_camera* c1, cons
 /* The same for rows of a frame that are held as a raster of their own (a strip of a frame split over GPUs):
  * triangulates rows [row0, row0+nrows) of d_disp / d_peak (rasters `width` wide, no pair needs to be bound), whose
  * row k is row k + frame_row0 of the frame the cameras describe, into the same rows of d_xyz (3 floats per pixel).
- * A strip triangulated this way equals the same rows of the whole frame's result bit for bit.  nrows <= 65535. */
+ * A strip triangulated this way equals the same rows of the whole frame's result bit for bit.  frame_row0 >= 0. */
 int mis_triangulate_disparity_rows_device(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
                                           const float* d_disp, const float* d_peak, float min_peak, int flags,
                                           int width, int row0, int nrows, int frame_row0,
@@ -227,7 +227,7 @@ int mis_triangulate_disparity_rows_device(mis_ctx* ctx, const mis_camera* c1, co
  * every call): calls that overlap in time on one GPU, from any context or stream, race on the count;
  * the XYZ output does not depend on it. */
 #define MIS_NOALLOC_MAX_WIDTH 65536
-#define MIS_NOALLOC_MAX_HEIGHT 65535
+#define MIS_NOALLOC_MAX_HEIGHT 65536
 int mis_triangulate_disparity_noalloc(mis_ctx* ctx, const mis_camera* c1, const mis_camera* c2,
                                       const float* d_disp, const float* d_peak, float min_peak,
                                       int width, int height, float* d_xyz, long long* d_n_matched);

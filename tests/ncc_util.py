@@ -33,23 +33,27 @@ def compare_ncc(gpu, ora, volume=None, dmin=None, check_peak2=False):
     gp, op = gpu["peak"][same], ora["peak"][same]
     assert np.all(np.abs(gp - op) <= PEAK_RTOL * np.maximum(np.abs(op), 1e-3) + 2e-6), \
         "peak mismatch: max abs %g" % np.abs(gp - op).max()
+    # subpixel: NO pixel is excluded from the comparison.  Every outlier is then classified, as oracle.parity_report
+    # does for the benchmark line: it must be an ill-conditioned parabola (denominator |s- - 2 s0 + s+| below 1e-4 in
+    # the oracle's float64 volume, where float32 noise of the three scores moves the vertex); the count is returned.
     gd, od = gpu["disp"][same], ora["disp"][same]
-    # a flat parabola (neighbours within float noise of the peak) has no stable vertex: skip those
-    if "flat" in ora:
-        ok = ~ora["flat"][same]
-        gd, od = gd[ok], od[ok]
-    assert np.all(np.abs(gd - od) <= SUBPX_ATOL), "subpixel mismatch: max %g" % np.abs(gd - od).max()
+    bad = np.abs(gd - od) > SUBPX_ATOL
+    if bad.any():
+        assert "flat" in ora, "subpixel mismatch on %d pixels: max %g (no volume to classify them)" % (bad.sum(), np.abs(gd - od).max())
+        well = bad & ~ora["flat"][same]
+        assert not well.any(), "subpixel mismatch on %d well-conditioned pixels: max %g" % (well.sum(), np.abs(gd - od)[well].max())
     assert np.array_equal(gpu["disp"][~valid], ora["disp"][~valid])
     assert np.array_equal(gpu["peak"][~valid], ora["peak"][~valid])
     if check_peak2:
         g2, o2 = gpu["peak2"][same], ora["peak2"][same]
         assert np.all(np.abs(g2 - o2) <= PEAK_RTOL * np.maximum(np.abs(o2), 1e-3) + 2e-6), \
             "peak2 mismatch: max abs %g" % np.abs(g2 - o2).max()
-    return {"valid": nvalid, "agree": float(agree)}
+    return {"valid": nvalid, "agree": float(agree), "subpx_outliers_ill_conditioned": int(bad.sum())}
 
 
 def flat_mask(volume, idisp, dmin, eps=1e-4):
-    """Pixels whose parabola denominator is below eps: the subpixel vertex is ill-conditioned."""
+    """Conditioning class of every pixel's parabola (the one oracle.parity_report uses): True where the denominator is
+    below eps, so the subpixel vertex is ill-conditioned.  compare_ncc uses it to classify outliers, not to skip pixels."""
     h, w, nd = volume.shape
     k = np.clip(idisp.astype(np.int64) - dmin, 0, nd - 1)
     yy, xx = np.mgrid[0:h, 0:w]
