@@ -249,3 +249,27 @@ def test_nearly_parallel_rays(ctx, d):
     n = ctx.triangulate_disparity_torch(mistereo.make_camera(*c1), mistereo.make_camera(*c2), disp, peak, MIN_PEAK, xyz)
     ctx.synchronize()
     assert _check(disp.cpu().numpy(), peak.cpu().numpy(), xyz.cpu().numpy(), n, c1, c2) == h * w
+
+
+def test_rasters_higher_than_one_launch_covers(ctx):
+    """A launch covers at most 65535 rows: a 65536-row raster (the highest a pair may be) is triangulated in slabs, and
+    equals its two halves triangulated as strips of the frame; a negative frame row offset is refused."""
+    import torch
+    h, w = 65536, 8
+    rng = np.random.default_rng(3)
+    disp = torch.from_numpy(rng.integers(-30, 31, (h, w)).astype(np.float32)).cuda()
+    peak = torch.from_numpy(rng.uniform(0.5, 1.0, (h, w)).astype(np.float32)).cuda()
+    c1, c2 = (mistereo.make_camera(*c) for c in _cameras(w, h, 60.0))
+    whole = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    halves = torch.ones((h, w, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    n = ctx.triangulate_disparity_rows_torch(c1, c2, disp, peak, MIN_PEAK, whole, 0, h, 0)
+    # the lower half held as a raster of its own: its row k is frame row k + h/2
+    n0 = ctx.triangulate_disparity_rows_torch(c1, c2, disp, peak, MIN_PEAK, halves, 0, h // 2, 0)
+    n1 = ctx.triangulate_disparity_rows_torch(c1, c2, disp[h // 2:], peak[h // 2:], MIN_PEAK, halves[h // 2:], 0, h // 2, h // 2)
+    ctx.synchronize()
+    assert n == n0 + n1 == int((peak >= MIN_PEAK).sum().item())
+    a, b = whole.cpu().numpy().view(np.uint32), halves.cpu().numpy().view(np.uint32)
+    assert np.array_equal(a, b)
+    with pytest.raises(mistereo.MisError):
+        ctx.triangulate_disparity_rows_torch(c1, c2, disp, peak, MIN_PEAK, whole, 0, 16, -1)

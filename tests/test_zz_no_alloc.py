@@ -75,7 +75,7 @@ def test_noalloc_count_is_optional_and_limits_are_checked():
                                                    C.c_void_p(xyz.data_ptr()), None)
         assert rc == 1 and b"outside the supported" in lib.mis_last_error(ctx._h)
         rc = lib.mis_triangulate_disparity_noalloc(ctx._h, C.byref(c1), C.byref(c2), C.c_void_p(disp.data_ptr()),
-                                                   C.c_void_p(peak.data_ptr()), C.c_float(0.75), 4, 65536,
+                                                   C.c_void_p(peak.data_ptr()), C.c_float(0.75), 4, 65537,
                                                    C.c_void_p(xyz.data_ptr()), None)
         assert rc == 1
     finally:
