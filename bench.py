@@ -183,43 +183,34 @@ def issue_floor(W, H, window, nd, kernel_s):
     profiles/), plus the issue slots of 18 MFMAs (8 cycles each); a warm-up row is the 18 MFMAs alone
     (32 cycles each at the 2.1 GHz the kernel holds).  Wavefronts: 64-column blocks x ranges of 96 right
     columns x bands of rows (the library's rule), 1024 SIMDs.
-    Wider windows (vector kernel, 21x21 figures): 509 ns of SIMD time per strip row of 32 columns x 64
-    disparities (dot2c 94, DPP maxima 93, sliding sums 89, packed fmas 86, keys 58, rest 90)."""
+    Windows beyond 21 x 21: one more v_fma_f32 per register and 4 products per tile instead of 3."""
     r = window // 2
     rows = H - 2 * r
-    if window <= 21:
-        blocks = -(-(W - 2 * r) // 64)
-        ranges = (((nd + 30) >> 5) + 2 + 2) // 3
-        band = 256
-        while band > 32 and blocks * ranges * -(-rows // band) < 4 * 2048:
-            band //= 2
-        bands = -(-rows // band)
-        scored_ns = 96 * (1.05 + 1.05 + 1.8 + 0.9) + 18 * 8 / 2.1
-        warm_ns = 18 * 32 / 2.1
-        floor_s = blocks * ranges * (rows * scored_ns + bands * 2 * r * warm_ns) * 1e-9 / 1024
-        return {"ms": round(floor_s * 1e3, 3), "frac": round(floor_s / kernel_s, 3) if kernel_s > 0 else None,
-                "note": "vector-issue floor of the matrix-core kernel's instruction mix (prices at 8 wavefronts per SIMD; "
-                        "the kernel's 96 accumulators allow 2) / measured kernel time"}
-    if window != 21:
-        return None
-    strips = -(-(W - 2 * r) // 32)
-    chunks = nd // 64
-    band = 256 if strips * -(-rows // 256) * max(chunks, 1) >= 6 * 5120 else 128      # the library's rule
+    blocks = -(-(W - 2 * r) // 64)
+    ranges = (((nd + 30) >> 5) + 2 + 2) // 3
+    band = 256
+    while band > 32 and blocks * ranges * -(-rows // band) < 4 * 2048:
+        band //= 2
     bands = -(-rows // band)
-    strip_rows = strips * chunks * (rows + bands * 2 * r * 0.37)      # warm-up rows run the column sums only (37 % of a row)
-    floor_s = strip_rows * 509e-9 / 1024
+    # windows beyond 21 x 21: one more v_fma_f32 per register (the mean correction's integer part), no spare taps
+    ks = (2 * r + 1 + (2 if window <= 21 else 0) + 7) // 8
+    per_reg = 1.05 + 1.05 + 1.8 + 0.9 + (0.0 if window <= 21 else 1.05)
+    scored_ns = 96 * per_reg + 6 * ks * 8 / 2.1
+    warm_ns = 6 * ks * 32 / 2.1
+    floor_s = blocks * ranges * (rows * scored_ns + bands * 2 * r * warm_ns) * 1e-9 / 1024
     return {"ms": round(floor_s * 1e3, 3), "frac": round(floor_s / kernel_s, 3) if kernel_s > 0 else None,
-            "note": "vector-issue floor of the kernel's instruction mix / measured kernel time"}
+            "note": "vector-issue floor of the matrix-core kernel's instruction mix (prices at 8 wavefronts per SIMD; "
+                    "the kernel's 96 accumulators allow 2) / measured kernel time"}
 
 
 def mfma_rate(W, H, window, nd, kernel_s):
-    """Matrix-core work of the argmax kernels (windows up to 21): one 32x32x16 f16 product per 8 window taps
-    (the window's taps and two spare ones that carry the mean correction), tile and row: 2 * 16 * KS flop per
+    """Matrix-core work of the argmax kernels: one 32x32x16 f16 product per 8 window taps (up to 21 x 21: the
+    window's taps and two spare ones that carry the mean correction), tile and row: 2 * 16 * KS flop per
     pixel and disparity, against the dense f16 peak."""
-    if window > 21 or kernel_s <= 0:
+    if kernel_s <= 0:
         return None
     r = window // 2
-    ks = (2 * r + 1 + 2 + 7) // 8
+    ks = (2 * r + 1 + (2 if window <= 21 else 0) + 7) // 8
     flop = 2.0 * 16 * ks * (W - 2 * r) * (H - 2 * r) * nd
     return {"flop": flop, "achieved_tflops": round(flop / kernel_s / 1e12, 1), "peak_tflops": 2500.0,
             "frac": round(flop / kernel_s / 2.5e15, 4), "note": "the products are not the bound: the vector unit that turns "
@@ -791,7 +782,7 @@ def main():
         kernel_s = (main_ms / max(calls, 1)) / 1e3
         alg_bytes = ALG_BYTES_PER_PX_U8 * rows_rank0 * W
         achieved = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-        kname = "ncc_mfma_argmax_kernel" if args.window <= 21 else "ncc_argmax_kernel"
+        kname = "ncc_mfma_argmax_kernel" if os.environ.get("MISTEREO_NCC_MFMA", "1") != "0" else "ncc_argmax_kernel"
         wl = ("BASELINE config[1]" if (W, args.window, D) == (8192, 21, 256) else
               "BASELINE config[3] frame size (one of its 16 pairs)" if (W, args.window, D) == (16384, 21, 256) else "non-baseline size")
         result = {

@@ -15,8 +15,10 @@
 // (s1, s0) of this and of the previous row, B carries (256 c, c) and -(256 c, c); they sit in the two taps the
 // products have to spare behind the window's last tap.  Every value is an integer, exact in f16 as an operand,
 // and every partial sum stays below 2^24 (|S| and |c S_R| <= 128^2 * 441), so the accumulators hold T exactly
-// in whatever order the matrix unit adds.  Windows wider than 21 do not keep that bound and stay on the
-// vector kernel.
+// in whatever order the matrix unit adds.  Windows wider than 21 do not keep that bound for T (|S| and |c S_R| reach
+// 128^2 * 961 each, their partial sums 2^25): there only S slides on the matrix cores -- its partial sums stay below
+// 32 * 31 * 128^2 < 2^24 for windows up to 31 x 31 -- and T = fma(c, S_R, S) is one more vector instruction per
+// register, exact because T itself is an integer below 2^24 (|T| <= |cov| + |S_R| / 2).
 //
 //   wavefront   <-> 64 left columns (two 32-column blocks) x one range of 32*T right columns x a band of rows
 //   accumulators<-> T x 2 tiles of 32 x 32 values of T(x, x'); column x on the lane, right column x' in the registers
@@ -47,11 +49,13 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #define NCC_MF_T 3           // 32-column tiles of right columns per wavefront
 #define NCC_MF_NB 2          // 32-column blocks of left columns per wavefront
 #define NCC_MF_LOW (-3.0e38f)
-#define NCC_MF_MAX_R 10      // widest window whose partial sums stay below 2^24
+#define NCC_MF_MAX_R 15      // widest window whose window sums S keep their partial sums below 2^24
+#define NCC_MF_CORR_MAX_R 10 // widest window whose corrected sums T = S + c S_R do too: the correction rides the products
 
 template <int R>
 struct NccMfCfg {
-    static constexpr int KS = (2 * R + 1 + 2 + 7) / 8;          // products of 8 taps (16 k) per row step: the window's taps and two spare ones
+    static constexpr bool CORR = R <= NCC_MF_CORR_MAX_R;        // the integer part of the mean correction rides the products
+    static constexpr int KS = (2 * R + 1 + (CORR ? 2 : 0) + 7) / 8;   // products of 8 taps (16 k) per row step: the window's taps (and two spare ones)
     static constexpr int SEGR = 32 * NCC_MF_T + 8 * KS;         // staged right pixels
     static constexpr int SEGL = 32 * NCC_MF_NB + 8 * KS;        // staged left pixels
     static constexpr int QR = SEGR / 4, QL = SEGL / 4;          // 16-byte positions per copy
@@ -78,15 +82,19 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     using Cfg = NccMfCfg<R>;
     constexpr int KS = Cfg::KS, T = NCC_MF_T, NB = NCC_MF_NB, CS = Cfg::CS, QR = Cfg::QR, QL = Cfg::QL;
     constexpr int WN = 2 * R + 1;
+    constexpr bool CORR = Cfg::CORR;
     static_assert(R <= NCC_MF_MAX_R, "partial sums must stay below 2^24");
+    static_assert(32 * (2 * R + 1) * 128 * 128 < (1 << 24), "partial sums of S: window, entering and leaving row");
     static_assert(NB == 2, "the half-wave merge pairs two column blocks");
     static_assert(16 * T <= 64, "register tags are inline constants");
-    static_assert(8 * KS - 2 > 2 * R, "two spare taps behind the window");
+    static_assert(!CORR || 8 * KS - 2 > 2 * R, "two spare taps behind the window");
+    static_assert(8 * KS > 2 * R, "the products cover the window's taps");
     __shared__ __attribute__((aligned(16))) float sR[4 * CS];
     __shared__ __attribute__((aligned(16))) float sL[4 * CS];
     __shared__ __attribute__((aligned(16))) float sIr[32 * T];          // 1 / sigma_R of the row being scored
     __shared__ __attribute__((aligned(16))) float sQ[32 * T];           // S_R / sigma_R
-    __shared__ __attribute__((aligned(16))) uint32_t sC[2][32 * T];     // half2(s1, s0) of S_R, rows of even / odd parity
+    __shared__ __attribute__((aligned(16))) uint32_t sC[2][CORR ? 32 * T : 4];   // CORR: half2(s1, s0) of S_R, rows of even / odd parity
+    __shared__ __attribute__((aligned(16))) float sSr[CORR ? 4 : 32 * T];        // otherwise: S_R of the row being scored
 
     const int lane = threadIdx.x, n = lane & 31, h = lane >> 5;
     // Workgroups are dealt to the 8 XCDs round-robin; remap so that every XCD works through a contiguous
@@ -206,19 +214,23 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         if (okT) {
             const f32x4_t srv = __builtin_bit_cast(f32x4_t, fsr), irv = __builtin_bit_cast(f32x4_t, fir);
             const f32x4_t q4 = srv * irv;
-            const f32x4_t s1v = __builtin_elementwise_floor(srv * (1.0f / 256.0f));
-            const f32x4_t s0v = srv - 256.0f * s1v;      // exact: integers below 2^17
-            uint32_t pk[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                half2_t p;
-                p.x = (_Float16)s1v[e]; p.y = (_Float16)s0v[e];
-                pk[e] = __builtin_bit_cast(uint32_t, p);
-            }
-            const u32x4_t cv = { pk[0], pk[1], pk[2], pk[3] };
-            *(u32x4_t*)(sIr + 4 * lane) = fir;
+            *(f32x4_t*)(sIr + 4 * lane) = irv;
             *(f32x4_t*)(sQ + 4 * lane) = q4;
-            *(u32x4_t*)(&sC[row & 1][4 * lane]) = cv;
+            if constexpr (CORR) {
+                const f32x4_t s1v = __builtin_elementwise_floor(srv * (1.0f / 256.0f));
+                const f32x4_t s0v = srv - 256.0f * s1v;      // exact: integers below 2^17
+                uint32_t pk[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    half2_t p;
+                    p.x = (_Float16)s1v[e]; p.y = (_Float16)s0v[e];
+                    pk[e] = __builtin_bit_cast(uint32_t, p);
+                }
+                const u32x4_t cv = { pk[0], pk[1], pk[2], pk[3] };
+                *(u32x4_t*)(&sC[row & 1][4 * lane]) = cv;
+            } else {
+                *(f32x4_t*)(sSr + 4 * lane) = srv;
+            }
         }
     };
 
@@ -236,7 +248,8 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[t][c][i] = 0.f;
     // (s1, s0) slots start finite: they are multiplied by zero until the first scored row
-    for (int i = lane; i < 2 * 32 * T; i += 64) (&sC[0][0])[i] = 0u;
+    if constexpr (CORR)
+        for (int i = lane; i < 2 * 32 * T; i += 64) (&sC[0][0])[i] = 0u;
 
     // left operands of the current row: B[k][x], 8 k per lane and product.  The last product's two spare taps
     // (upper half-wave, elements 2 and 3) carry the correction pairs cur = (256 c, c) and prv = -(256 c, c) of the
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int tap0 = 8 * kk + e, tap1 = tap0 + 4;        // this element's tap in the lower / upper half-wave
-                    if (kk == KS - 1 && e >= 2) {
+                    if (CORR && kk == KS - 1 && e >= 2) {
                         const uint32_t lo = tap0 > 2 * R ? 0u : v[e];
                         v[e] = h ? (e == 2 ? cur[c] : prv[c]) : lo;
                     } else if (tap0 > 2 * R) v[e] = 0u;
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     auto load_a = [&](int t, u32x4_t (&aop)[KS], int row) {
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) aop[kk] = *(const u32x4_t*)(sR + oLane + 32 * t + 8 * kk);
+        if constexpr (!CORR) return;
         uint32_t ccur = sC[row & 1][32 * t + n], cprv = sC[(row & 1) ^ 1][32 * t + n];
         asm volatile("" : "+v"(ccur), "+v"(cprv));   // both reads in every lane: inside a branch on h they would wait for all earlier reads
         aop[KS - 1][2] = h ? ccur : aop[KS - 1][2];
@@ -357,9 +371,10 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         if (EDGE) asm volatile("" : "+s"(ab), "+s"(pb));        // tested bit by bit where needed, not as a dozen loop-invariant lane masks
         const int ynew = yb0 - R + st, yout = ynew - R;
         const float ng[NB] = { fng[0], fng[1] };     // fetched with this row's operands during the previous step
+        const float nc[NB] = { fnc[0], fnc[1] };
         uint32_t ccur[NB];
 #pragma unroll
-        for (int c = 0; c < NB; c++) ccur[c] = cpair(fnc[c]);
+        for (int c = 0; c < NB; c++) ccur[c] = CORR ? cpair(fnc[c]) : 0u;
         fetch(ynew + 1);
         u32x4_t bop[NB][KS];
         load_b(bop, ccur, cprev);
@@ -378,11 +393,12 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
             if (EDGE && !((ab >> (t * NB)) & ((1u << NB) - 1u))) continue;
             u32x4_t aop[KS];
             load_a(t, aop, yout);
-            f32x4_t irv[4], qv[4];
+            f32x4_t irv[4], qv[4], srv[4];
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 irv[b] = *(const f32x4_t*)(sIr + 32 * t + 8 * b + 4 * h);
                 qv[b] = *(const f32x4_t*)(sQ + 32 * t + 8 * b + 4 * h);
+                if constexpr (!CORR) srv[b] = *(const f32x4_t*)(sSr + 32 * t + 8 * b + 4 * h);
             }
 #pragma unroll
             for (int c = 0; c < NB; c++)
@@ -405,11 +421,62 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
                         ir[i] = in ? ir[i] : __builtin_bit_cast(float, qnan);
                     }
                 }
+                // The matrix unit's results may not be read by a vector instruction before the product has drained (wait
+                // states that software must insert).  The compiler counts them for instructions it emits itself, not for
+                // the text of an asm statement, and its scheduler moves the products right in front of the statements that
+                // read their accumulators.  So one instruction of the compiler's own reads the tile first (it gets the
+                // wait states), and every statement below takes its result as an operand, which orders them behind it.
+                const float drained = __builtin_fmaf(acc[t][c][0], 0.f, 0.f);
                 // one statement per 4 registers (the compiler pads every asm statement with a wait state of its own):
                 // p = g * (S_R / sigma_R), score = fma(T, 1 / sigma_R, p), key, running maximum
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float k0, k1, k2, k3;
+                    if constexpr (!CORR) {
+                        // windows beyond 21 x 21: the accumulators hold S; T = fma(c, S_R, S) (exact), score = T / sigma_R + g S_R / sigma_R
+                        asm("v_fma_f32 %0, %8, %10, %4\n\t"
+                            "v_fma_f32 %1, %8, %11, %5\n\t"
+                            "v_fma_f32 %2, %8, %12, %6\n\t"
+                            "v_fma_f32 %3, %8, %13, %7\n\t"
+                            "v_mul_f32 %0, %0, %18\n\t"
+                            "v_mul_f32 %1, %1, %19\n\t"
+                            "v_mul_f32 %2, %2, %20\n\t"
+                            "v_mul_f32 %3, %3, %21\n\t"
+                            "v_fmac_f32 %0, %9, %14\n\t"
+                            "v_fmac_f32 %1, %9, %15\n\t"
+                            "v_fmac_f32 %2, %9, %16\n\t"
+                            "v_fmac_f32 %3, %9, %17\n\t"
+                            "v_and_or_b32 %0, %0, %22, %23\n\t"
+                            "v_and_or_b32 %1, %1, %22, %24\n\t"
+                            "v_and_or_b32 %2, %2, %22, %25\n\t"
+                            "v_and_or_b32 %3, %3, %22, %26"
+                            : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3)
+                            : "v"(acc[t][c][4 * j]), "v"(acc[t][c][4 * j + 1]), "v"(acc[t][c][4 * j + 2]), "v"(acc[t][c][4 * j + 3]),
+                              "v"(nc[c]), "v"(ng[c]), "v"(srv[j][0]), "v"(srv[j][1]), "v"(srv[j][2]), "v"(srv[j][3]),
+                              "v"(qv[j][0]), "v"(qv[j][1]), "v"(qv[j][2]), "v"(qv[j][3]),
+                              "v"(ir[4 * j]), "v"(ir[4 * j + 1]), "v"(ir[4 * j + 2]), "v"(ir[4 * j + 3]), "s"(kmask),
+                              "n"(16 * t + 4 * j), "n"(16 * t + 4 * j + 1), "n"(16 * t + 4 * j + 2), "n"(16 * t + 4 * j + 3), "v"(drained));
+                        if constexpr (WANT2) {
+                            const int L = (2 * t + 2 * j) % 3;
+                            float &A1 = m1[c][L], &A2 = m2[c][L], &B1 = m1[c][(L + 1) % 3], &B2 = m2[c][(L + 1) % 3],
+                                  &C1 = m1[c][(L + 2) % 3], &C2 = m2[c][(L + 2) % 3];
+                            asm("v_med3_f32 %1, %0, %1, %6\n\t"
+                                "v_med3_f32 %3, %2, %3, %7\n\t"
+                                "v_med3_f32 %5, %4, %5, %8\n\t"
+                                "v_max_f32 %0, %0, %6\n\t"
+                                "v_max_f32 %2, %2, %7\n\t"
+                                "v_max_f32 %4, %4, %8\n\t"
+                                "v_med3_f32 %1, %0, %1, %9\n\t"
+                                "v_max_f32 %0, %0, %9"
+                                : "+v"(A1), "+v"(A2), "+v"(B1), "+v"(B2), "+v"(C1), "+v"(C2)
+                                : "v"(k0), "v"(k1), "v"(k2), "v"(k3));
+                        } else {
+                            asm("v_max3_f32 %0, %0, %1, %2\n\t"
+                                "v_max3_f32 %0, %0, %3, %4"
+                                : "+v"(best[c]) : "v"(k0), "v"(k1), "v"(k2), "v"(k3));
+                        }
+                        continue;
+                    }
                     if constexpr (WANT2) {
                         // the four registers' labels are L, L+1, L+2, L (mod 3): best two per class by v_med3 / v_max
                         const int L = (2 * t + 2 * j) % 3;
@@ -439,7 +506,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
                             : "v"(acc[t][c][4 * j]), "v"(acc[t][c][4 * j + 1]), "v"(acc[t][c][4 * j + 2]), "v"(acc[t][c][4 * j + 3]),
                               "v"(ng[c]), "v"(qv[j][0]), "v"(qv[j][1]), "v"(qv[j][2]), "v"(qv[j][3]),
                               "v"(ir[4 * j]), "v"(ir[4 * j + 1]), "v"(ir[4 * j + 2]), "v"(ir[4 * j + 3]), "s"(kmask),
-                              "n"(16 * t + 4 * j), "n"(16 * t + 4 * j + 1), "n"(16 * t + 4 * j + 2), "n"(16 * t + 4 * j + 3));
+                              "n"(16 * t + 4 * j), "n"(16 * t + 4 * j + 1), "n"(16 * t + 4 * j + 2), "n"(16 * t + 4 * j + 3), "v"(drained));
                         continue;
                     }
                     asm("v_mul_f32 %1, %9, %10\n\t"
@@ -460,7 +527,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
                         : "v"(acc[t][c][4 * j]), "v"(acc[t][c][4 * j + 1]), "v"(acc[t][c][4 * j + 2]), "v"(acc[t][c][4 * j + 3]),
                           "v"(ng[c]), "v"(qv[j][0]), "v"(qv[j][1]), "v"(qv[j][2]), "v"(qv[j][3]),
                           "v"(ir[4 * j]), "v"(ir[4 * j + 1]), "v"(ir[4 * j + 2]), "v"(ir[4 * j + 3]), "s"(kmask),
-                          "n"(16 * t + 4 * j), "n"(16 * t + 4 * j + 1), "n"(16 * t + 4 * j + 2), "n"(16 * t + 4 * j + 3));
+                          "n"(16 * t + 4 * j), "n"(16 * t + 4 * j + 1), "n"(16 * t + 4 * j + 2), "n"(16 * t + 4 * j + 3), "v"(drained));
                 }
             }
         }

@@ -208,9 +208,10 @@ def test_random_shapes_windows_and_ranges(ctx, seed):
     _run(ctx, left, right, window, dmin, dmax)
 
 
-@pytest.mark.parametrize("window", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21])
+@pytest.mark.parametrize("window", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31])
 def test_every_window_of_the_matrix_core_path(ctx, window):
-    """8-bit windows up to 21 x 21 run the matrix-core argmax kernels.  Search ranges that end on, just before
+    """Every 8-bit window runs the matrix-core argmax kernels: up to 21 x 21 with the integer part of the mean correction
+    inside the products, from 23 x 23 on with that correction as a vector instruction per score.  Search ranges that end on, just before
     and just past the kernels' 32-disparity tile grid and 96-column ranges, from one disparity to several key
     planes, on a width that is no multiple of the 64-column blocks."""
     rng = np.random.default_rng(window)
@@ -234,7 +235,7 @@ def test_widest_search_range_on_the_matrix_core_path(ctx):
     _run(ctx, left, right, 11, 0, 2047)
 
 
-@pytest.mark.parametrize("window", [9, 21])
+@pytest.mark.parametrize("window", [9, 21, 23, 31])
 def test_extreme_contrast_at_the_accumulator_bound(ctx, window):
     """Black-and-white images drive the window sums and the mean corrections of the matrix-core kernels to
     their largest magnitudes (128^2 per pixel): every partial sum must still be exact in f32."""
@@ -246,6 +247,9 @@ def test_extreme_contrast_at_the_accumulator_bound(ctx, window):
     base[:, 300:330] = np.where(rng.random((h, 30)) < 0.03, 0, 255)      # nearly saturated, small variance
     left = np.ascontiguousarray(base[:, 40:40 + w])
     right = np.ascontiguousarray(base[:, 40 + 13:40 + 13 + w])
+    _run(ctx, left, right, window, -64, 64)
+    # all-black against all-white runs: every product is 128 * 128 or -128 * 127, the window sums at their bound
+    left[:, 100:180] = 0
     _run(ctx, left, right, window, -64, 64)
 
 
