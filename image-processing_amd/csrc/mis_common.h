@@ -48,7 +48,15 @@ struct mis_ctx {
     hipEvent_t strip_done[8] = {};
     void* pinned = nullptr;               // two staging slots of MIS_STAGE_BYTES each (page-locked)
     hipEvent_t slot_ready[2] = {};
+    // mis_upload_pair from page-locked rasters: the pair travels in row chunks on up_stream while the call returns;
+    // chunk k (rows below up_rows[k] of both rasters) has arrived when up_done[k] completes.  up_n == 0: nothing in flight.
+    hipStream_t up_stream = nullptr;
+    hipEvent_t up_done[8] = {}, up_start = nullptr;
+    int up_rows[8] = {};
+    int up_n = 0;
 };
+// orders `s` behind the arrival of rows [0, row_hi) of a pair that mis_upload_pair left in flight (no-op otherwise)
+int mis_wait_upload(mis_ctx* ctx, int row_hi, hipStream_t s);
 #define MIS_STAGE_BYTES ((size_t)32 << 20)
 
 // One piece of a device -> pageable host copy.
@@ -57,14 +65,18 @@ struct MisCopyJob { void* dst; const void* src; size_t bytes; hipEvent_t after; 
 // of one piece overlaps the host-side copy (several threads) of the previous one.  A job starts once
 // its `after` event (may be null) has completed.  Returns when everything has arrived.
 int mis_copy_back(mis_ctx* ctx, const MisCopyJob* jobs, int njobs);
+// true when [p, p + bytes) is page-locked host memory the device can copy to and from directly
+bool mis_host_pinned(const void* p, size_t bytes);
 
 int mis_fail(mis_ctx* ctx, int code, const char* fmt, ...);
 #define MIS_HIP(ctx, call)                                                             \
     do {                                                                               \
         hipError_t e_ = (call);                                                        \
-        if (e_ != hipSuccess)                                                          \
+        if (e_ != hipSuccess) {                                                        \
+            (void)hipGetLastError(); /* reported here: a later launch check must not see it again */ \
             return mis_fail((ctx), MIS_ERR_DEVICE, "%s failed: %s (%s:%d)", #call,     \
                             hipGetErrorString(e_), __FILE__, __LINE__);                \
+        }                                                                              \
     } while (0)
 
 // grows *buf to at least `bytes` (device memory); contents are not preserved

@@ -11,6 +11,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <map>
 #include <mutex>
 
 static std::string g_create_err;
@@ -74,9 +75,46 @@ static void host_copy_parallel(void* dst, const void* src, size_t bytes)
     for (auto& t : th) t.join();
 }
 
+// ranges page-locked by mis_pin_host: the caller's pointer -> the page-aligned base that was registered
+static std::mutex g_pin_mu;
+static std::map<void*, void*> g_pinned;
+
+// true when [p, p + bytes) is page-locked host memory the device can copy to directly (mis_pin_host, hipHostRegister
+// or hipHostMalloc by the caller); pageable memory makes hipPointerGetAttributes fail, which is not an error here
+bool mis_host_pinned(const void* p, size_t bytes)
+{
+    if (!p || !bytes) return false;
+    hipPointerAttribute_t a0, a1;
+    if (hipPointerGetAttributes(&a0, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipPointerGetAttributes(&a1, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost;
+}
+
+int mis_wait_upload(mis_ctx* ctx, int row_hi, hipStream_t s)
+{
+    for (int k = 0; k < ctx->up_n; k++)
+        if (ctx->up_rows[k] >= row_hi || k == ctx->up_n - 1) {
+            MIS_HIP(ctx, hipStreamWaitEvent(s, ctx->up_done[k], 0));
+            break;
+        }
+    return MIS_OK;
+}
+
 int mis_copy_back(mis_ctx* ctx, const MisCopyJob* jobs, int njobs)
 {
     if (!ctx->copy_stream) MIS_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    {
+        // every destination page-locked: the device writes straight into the caller's rasters, no staging, no host copy
+        bool all_pinned = njobs > 0;
+        for (int j = 0; j < njobs && all_pinned; j++) all_pinned = mis_host_pinned(jobs[j].dst, jobs[j].bytes);
+        if (all_pinned) {
+            for (int j = 0; j < njobs; j++) {
+                if (jobs[j].after) MIS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, jobs[j].after, 0));
+                MIS_HIP(ctx, hipMemcpyAsync(jobs[j].dst, jobs[j].src, jobs[j].bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+            }
+            return MIS_OK;            // the caller synchronises the copy stream
+        }
+    }
     if (!ctx->pinned) {
         MIS_HIP(ctx, hipHostMalloc(&ctx->pinned, 2 * MIS_STAGE_BYTES, hipHostMallocDefault));
         for (int i = 0; i < 2; i++) MIS_HIP(ctx, hipEventCreateWithFlags(&ctx->slot_ready[i], hipEventDisableTiming));
@@ -110,6 +148,56 @@ int mis_copy_back(mis_ctx* ctx, const MisCopyJob* jobs, int njobs)
 }
 
 extern "C" {
+
+int mis_alloc_host(mis_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!out || !bytes) return mis_fail(ctx, MIS_ERR_ARG, "host allocation: empty request");
+    *out = nullptr;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    MIS_HIP(ctx, hipHostMalloc(out, bytes, hipHostMallocPortable));
+    return MIS_OK;
+}
+
+int mis_free_host(mis_ctx* ctx, void* ptr)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ptr) return MIS_OK;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    MIS_HIP(ctx, hipHostFree(ptr));
+    return MIS_OK;
+}
+
+int mis_pin_host(mis_ctx* ctx, void* ptr, size_t bytes)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ptr || !bytes) return mis_fail(ctx, MIS_ERR_ARG, "pin: empty range");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    if (mis_host_pinned(ptr, bytes)) return MIS_OK;
+    // whole pages: the range is widened to page boundaries (the neighbouring bytes of those pages are locked with it)
+    const uintptr_t page = 4096, lo = (uintptr_t)ptr & ~(page - 1), hi = ((uintptr_t)ptr + bytes + page - 1) & ~(page - 1);
+    MIS_HIP(ctx, hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    g_pinned[ptr] = (void*)lo;
+    return MIS_OK;
+}
+
+int mis_unpin_host(mis_ctx* ctx, void* ptr)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    if (!ptr) return mis_fail(ctx, MIS_ERR_ARG, "unpin: NULL");
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    void* base = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_pin_mu);
+        auto it = g_pinned.find(ptr);
+        if (it == g_pinned.end()) return mis_fail(ctx, MIS_ERR_STATE, "unpin: %p was not pinned by mis_pin_host", ptr);
+        base = it->second;
+        g_pinned.erase(it);
+    }
+    MIS_HIP(ctx, hipHostUnregister(base));
+    return MIS_OK;
+}
 
 int mis_profile_enable(mis_ctx* ctx, int on)
 {
@@ -189,6 +277,9 @@ int mis_destroy(mis_ctx* ctx)
     if (ctx->tri_buf) (void)hipFree(ctx->tri_buf);
     if (ctx->out_buf) (void)hipFree(ctx->out_buf);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->up_stream) { (void)hipStreamSynchronize(ctx->up_stream); (void)hipStreamDestroy(ctx->up_stream); }
+    if (ctx->up_start) (void)hipEventDestroy(ctx->up_start);
+    for (hipEvent_t e : ctx->up_done) if (e) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->slot_ready) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->strip_done) if (e) (void)hipEventDestroy(e);
@@ -218,6 +309,7 @@ int mis_synchronize(mis_ctx* ctx)
 {
     if (!ctx) return MIS_ERR_ARG;
     MIS_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->up_n) MIS_HIP(ctx, hipStreamSynchronize(ctx->up_stream));      // a pair left in flight by mis_upload_pair
     MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MIS_OK;
 }
@@ -250,6 +342,7 @@ int mis_bind_pair_device(mis_ctx* ctx, const void* d_img1, const void* d_img2, i
     ctx->img[0] = d_img1; ctx->img[1] = d_img2;
     ctx->dtype = dtype; ctx->width = width; ctx->height = height; ctx->stride = row_stride_bytes;
     ctx->pair_serial++;
+    ctx->up_n = 0;
     return MIS_OK;
 }
 
@@ -285,6 +378,32 @@ int mis_upload_pair(mis_ctx* ctx, const void* img1, const void* img2, int dtype,
         ctx->owned_img_bytes = bytes;
     }
     const void* src[2] = { img1, img2 };
+    if (row_stride_bytes == rowb && height >= 64 && mis_host_pinned(img1, bytes) && mis_host_pinned(img2, bytes)) {
+        // Page-locked rasters: the pair travels by DMA in row chunks on a stream of its own and the call returns at
+        // once; the entry points that read the pair wait (on the device) for the chunks that hold their rows, so the
+        // first strip of a dense correlation starts while the rest of the pair is still on its way.
+        constexpr int NCH = 8;
+        if (!ctx->up_stream) {
+            MIS_HIP(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+            MIS_HIP(ctx, hipEventCreateWithFlags(&ctx->up_start, hipEventDisableTiming));
+            for (int k = 0; k < NCH; k++) MIS_HIP(ctx, hipEventCreateWithFlags(&ctx->up_done[k], hipEventDisableTiming));
+        }
+        // the buffers may still be read by work queued on the context's stream
+        MIS_HIP(ctx, hipEventRecord(ctx->up_start, ctx->stream));
+        MIS_HIP(ctx, hipStreamWaitEvent(ctx->up_stream, ctx->up_start, 0));
+        rc = mis_bind_pair_device(ctx, ctx->owned_img[0], ctx->owned_img[1], dtype, width, height, rowb);
+        if (rc) return rc;
+        for (int k = 0; k < NCH; k++) {
+            const int y0 = (int)((long long)height * k / NCH), y1 = (int)((long long)height * (k + 1) / NCH);
+            for (int i = 0; i < 2; i++)
+                MIS_HIP(ctx, hipMemcpyAsync((char*)ctx->owned_img[i] + (size_t)y0 * rowb, (const char*)src[i] + (size_t)y0 * rowb,
+                                            (size_t)(y1 - y0) * rowb, hipMemcpyHostToDevice, ctx->up_stream));
+            MIS_HIP(ctx, hipEventRecord(ctx->up_done[k], ctx->up_stream));
+            ctx->up_rows[k] = y1;
+        }
+        ctx->up_n = NCH;
+        return MIS_OK;
+    }
     for (int i = 0; i < 2; i++) {
         if (row_stride_bytes == rowb)       // one contiguous block: much faster than a 2-D copy from pageable memory
             MIS_HIP(ctx, hipMemcpyAsync(ctx->owned_img[i], src[i], bytes, hipMemcpyHostToDevice, ctx->stream));

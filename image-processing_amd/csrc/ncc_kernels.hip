@@ -1259,6 +1259,10 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     if (nrows == 0) return MIS_OK;
 
     mis_prof_mark(ctx);
+    {   // a pair still on its way from page-locked host rasters: the rows this call reads must have arrived
+        int rcu = mis_wait_upload(ctx, (row0 + nrows + r < H) ? row0 + nrows + r : H, ctx->stream);
+        if (rcu) return rcu;
+    }
     // the 8-bit path runs its small kernels on a second stream
     const bool fast = (ctx->dtype == MIS_U8 && W >= window && H >= window);
     if (fast && !ctx->ncc) ctx->ncc = new NccWs();
@@ -1397,10 +1401,12 @@ int mis_ncc_dense_rows(mis_ctx* ctx, int window, int dmin, int dmax, int row0, i
     int16_t* di = idisp ? (int16_t*)((char*)ctx->out_buf + 3 * a4) : nullptr;
     // The frame is computed in row strips and every finished strip is copied back on a second stream
     // while the next ones are computed (the copy to host memory is longer than the computation).
-    constexpr int NS = 4;
+    // (page-locked outputs travel at the link's rate: more, shorter strips leave less of the last copy exposed)
+    constexpr int NSMAX = 8;
+    const int NS = mis_host_pinned(disp, n * 4) && mis_host_pinned(peak, n * 4) ? 8 : 4;
     if (!ctx->strip_done[0])
-        for (int i = 0; i < NS; i++) MIS_HIP(ctx, hipEventCreateWithFlags(&ctx->strip_done[i], hipEventDisableTiming));
-    int r0[NS + 1];
+        for (int i = 0; i < NSMAX; i++) MIS_HIP(ctx, hipEventCreateWithFlags(&ctx->strip_done[i], hipEventDisableTiming));
+    int r0[NSMAX + 1];
     for (int i = 0; i <= NS; i++) r0[i] = row0 + ((int)((long long)nrows * i / NS) & ~3);
     r0[NS] = row0 + nrows;
     for (int i = 0; i < NS && !rc; i++) {
@@ -1410,7 +1416,7 @@ int mis_ncc_dense_rows(mis_ctx* ctx, int window, int dmin, int dmax, int row0, i
     }
     hipError_t e = hipSuccess;
     if (!rc) {
-        MisCopyJob jobs[4 * NS];
+        MisCopyJob jobs[4 * NSMAX];
         int nj = 0;
         for (int i = 0; i < NS; i++) {
             if (r0[i + 1] <= r0[i]) continue;

@@ -1488,7 +1488,9 @@ static int xcorr_run(mis_ctx* ctx, const mis_rect* d_r1, const mis_rect* d_r2, i
     if (n < 0 || (n > 0 && (!d_r1 || !d_r2 || (!d_out && peak_stages)))) return mis_fail(ctx, MIS_ERR_ARG, "tile correlation: NULL buffer");
     if (n == 0) return MIS_OK;
     MIS_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_ws(ctx); if (rc) return rc;
+    int rc = mis_wait_upload(ctx, ctx->height, ctx->stream);      // tiles reach anywhere in a pair that may still be on its way
+    if (rc) return rc;
+    rc = ensure_ws(ctx); if (rc) return rc;
     XcPlan p;
     rc = make_plan(ctx, tile_w, tile_h, &p); if (rc) return rc;
     // batches bounded by a 2 GiB workspace (one tile minimum)

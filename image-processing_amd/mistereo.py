@@ -58,7 +58,7 @@ EXPORTS = [
     "mis_group_upload_pair", "mis_group_xcorr_tiles", "mis_group_disparity_map", "mis_triangulate_disparity_rows_device",
     "mis_disparity_map", "mis_write_xyz", "mis_write_xyz_ex", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
     "mis_set_extra_bands_device", "mis_upload_extra_bands", "mis_masked_peak",
-    "mis_profile_enable", "mis_profile_read", "mis_version",
+    "mis_profile_enable", "mis_profile_read", "mis_version", "mis_pin_host", "mis_unpin_host", "mis_alloc_host", "mis_free_host",
 ]
 
 _lib = None
@@ -87,6 +87,10 @@ def load_library():
         lib.mis_destroy.argtypes = [vp]
         lib.mis_set_stream.argtypes = [vp, vp]
         lib.mis_synchronize.argtypes = [vp]
+        lib.mis_pin_host.argtypes = [vp, vp, sz]
+        lib.mis_alloc_host.argtypes = [vp, sz, C.POINTER(vp)]
+        lib.mis_free_host.argtypes = [vp, vp]
+        lib.mis_unpin_host.argtypes = [vp, vp]
         lib.mis_upload_pair.argtypes = [vp, vp, vp, i32, i32, i32, sz]
         lib.mis_bind_pair_device.argtypes = [vp, vp, vp, i32, i32, i32, sz]
         lib.mis_ncc_dense.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
@@ -345,6 +349,29 @@ class Context:
         a, b, c, n = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
         self._check(self._lib.mis_profile_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
         return a.value, b.value, c.value, n.value
+
+    def alloc_host(self, shape, dtype):
+        """A numpy array over page-locked memory allocated by the library (free it with free_host(array))."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        self._check(self._lib.mis_alloc_host(self._h, max(n, 1), C.byref(p)))
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        self._host_allocs = getattr(self, "_host_allocs", {})
+        self._host_allocs[a.ctypes.data] = p.value
+        return a
+
+    def free_host(self, array):
+        p = self._host_allocs.pop(array.ctypes.data)
+        self._check(self._lib.mis_free_host(self._h, C.c_void_p(p)))
+
+    def pin_host(self, array):
+        """Page-lock a numpy array's memory (inputs that are uploaded, outputs that results are copied into)."""
+        self._check(self._lib.mis_pin_host(self._h, _np_ptr(array), array.nbytes))
+
+    def unpin_host(self, array):
+        self._check(self._lib.mis_unpin_host(self._h, _np_ptr(array)))
 
     def synchronize(self):
         self._check(self._lib.mis_synchronize(self._h))

@@ -73,6 +73,24 @@ int mis_synchronize(mis_ctx* ctx);
  * (image3.cpp:325-328, 979-980): the pair is copied to HBM once. */
 int mis_upload_pair(mis_ctx* ctx, const void* img1, const void* img2, int dtype,
                     int width, int height, size_t row_stride_bytes);
+/* When both rasters are page-locked (below) and tightly packed, mis_upload_pair returns with the copy IN FLIGHT
+ * (row chunks by DMA on a stream of its own); the entry points that read the pair wait on the device for the rows
+ * they need, so a dense correlation starts on the first rows while the last ones still travel.  The host must not
+ * change or free such rasters before mis_synchronize (or a later mis_upload_pair followed by it) has returned. */
+/* No counterpart in the reference (its rasters live in GDAL's block cache, image3.cpp:325-328).  Page-locked host
+ * memory for the rasters a host hands to the entry points that take host pointers (the pair it uploads, the rasters
+ * results are copied into): those entry points recognise such memory and move it by DMA straight from / to it
+ * instead of through pageable copies -- about twice the transfer rate, and result strips travel while later strips
+ * are computed.  Optional: every entry point works with pageable memory.
+ *   mis_alloc_host / mis_free_host   memory allocated page-locked (read the raster into it: it is ordinary memory
+ *                                    for the host); memory the caller allocated with hipHostMalloc works as well.
+ *   mis_pin_host / mis_unpin_host    page-lock a range the caller already owns (hipHostRegister).  Not every
+ *                                    system allows it (MIS_ERR_DEVICE then; carry on with pageable memory).  Unpin
+ *                                    before freeing the memory. */
+int mis_alloc_host(mis_ctx* ctx, size_t bytes, void** out);
+int mis_free_host(mis_ctx* ctx, void* ptr);
+int mis_pin_host(mis_ctx* ctx, void* ptr, size_t bytes);
+int mis_unpin_host(mis_ctx* ctx, void* ptr);
 /* Same, for rasters already in device memory (not copied; must stay valid while bound).
  * The dense-NCC entry points keep tables derived from the pixels (window statistics, packed copies)
  * from one call to the next and rebuild them only when a pair is bound: a caller that writes new

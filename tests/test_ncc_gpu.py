@@ -427,3 +427,51 @@ def test_vector_kernels_behind_the_switch(tmp_path):
     env = dict(os.environ, MISTEREO_NCC_MFMA="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_page_locked_host_rasters(ctx):
+    """mis_alloc_host: inputs uploaded and result strips copied back by DMA from / into page-locked rasters; the same
+    bits as through pageable memory, rows outside the requested strip untouched.  mis_pin_host page-locks memory the
+    caller already owns where the system allows it (it does not on every box: then the error is reported and the
+    pageable path still works)."""
+    h, w = 300, 1100
+    left = synth.texture(h, w, 808)
+    right = synth.shift_right_image(left, -19, fill_seed=9)
+    ctx.upload_pair(left, right)
+    want = ctx.ncc_dense(15, -40, 24, want_idisp=True, want_peak2=True)
+    pl, pr = ctx.alloc_host((h, w), np.uint8), ctx.alloc_host((h, w), np.uint8)
+    disp, peak, peak2 = (ctx.alloc_host((h, w), np.float32) for _ in range(3))
+    idisp = ctx.alloc_host((h, w), np.int16)
+    try:
+        pl[:] = left; pr[:] = right
+        for rep in range(2):
+            disp[:] = 777.0; peak[:] = 777.0; peak2[:] = 777.0; idisp[:] = 77
+            ctx.upload_pair(pl, pr)
+            ctx.ncc_dense_rows(15, -40, 24, 0, h, disp, peak, idisp, peak2)
+            for k, a in (("disp", disp), ("peak", peak), ("peak2", peak2)):
+                assert np.array_equal(a.view(np.uint32), want[k].view(np.uint32)), k
+            assert np.array_equal(idisp, want["idisp"])
+            disp[:] = 777.0
+            ctx.ncc_dense_rows(15, -40, 24, 100, 57, disp, peak)         # a strip: the other rows keep their contents
+            assert np.array_equal(disp[100:157].view(np.uint32), want["disp"][100:157].view(np.uint32))
+            assert (disp[:100] == 777.0).all() and (disp[157:] == 777.0).all()
+        # a page-locked output beside a pageable one: the staged path serves both
+        pageable = np.full((h, w), 5.0, np.float32)
+        ctx.ncc_dense_rows(15, -40, 24, 0, h, disp, pageable)
+        assert np.array_equal(pageable.view(np.uint32), want["peak"].view(np.uint32))
+        assert np.array_equal(disp.view(np.uint32), want["disp"].view(np.uint32))
+    finally:
+        for a in (pl, pr, disp, peak, peak2, idisp):
+            ctx.free_host(a)
+    own = np.full((h, w), 3.0, np.float32)
+    try:
+        ctx.pin_host(own)
+    except mistereo.MisError as e:
+        assert "hipHostRegister" in str(e)                   # this system does not page-lock foreign memory
+        return
+    ctx.pin_host(own)                                        # pinning a pinned range is not an error
+    ctx.ncc_dense_rows(15, -40, 24, 0, h, own, np.empty((h, w), np.float32))
+    assert np.array_equal(own.view(np.uint32), want["disp"].view(np.uint32))
+    ctx.unpin_host(own)
+    with pytest.raises(mistereo.MisError):
+        ctx.unpin_host(own)                                  # not pinned any more

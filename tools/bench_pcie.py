@@ -16,6 +16,21 @@ for it in range(3):
     t2 = time.perf_counter()
     print("upload %.1f ms, ncc_dense with host outputs %.1f ms, total %.1f ms -> %.1f Gpx*disp/s" % (
         (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3, size * size * (2 * D + 1) / (t2 - t0) / 1e9), flush=True)
+# the same with page-locked rasters (mis_alloc_host): inputs by DMA, result strips by DMA straight into the caller's rasters
+pl, pr = ctx.alloc_host((size, size), np.uint8), ctx.alloc_host((size, size), np.uint8)
+disp, peak = ctx.alloc_host((size, size), np.float32), ctx.alloc_host((size, size), np.float32)
+pl[:] = left; pr[:] = right
+for it in range(4):
+    t0 = time.perf_counter()
+    ctx.upload_pair(pl, pr)
+    t1 = time.perf_counter()
+    ctx.ncc_dense_rows(win, -D, D, 0, size, disp, peak)
+    t2 = time.perf_counter()
+    print("page-locked: upload %.1f ms, ncc_dense with host outputs %.1f ms, total %.1f ms -> %.1f Gpx*disp/s" % (
+        (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3, size * size * (2 * D + 1) / (t2 - t0) / 1e9), flush=True)
+assert np.array_equal(disp.view(np.uint32), out["disp"].view(np.uint32)) and np.array_equal(peak.view(np.uint32), out["peak"].view(np.uint32))
+for a in (pl, pr, disp, peak):
+    ctx.free_host(a)
 # the same through a group (one process over several GPUs; here every slot is GPU 0): strips in parallel host threads
 for slots in (1, 2, 4):
     g = mistereo.Group([0] * slots)
