@@ -415,6 +415,42 @@ int mis_upload_pair(mis_ctx* ctx, const void* img1, const void* img2, int dtype,
     return mis_bind_pair_device(ctx, ctx->owned_img[0], ctx->owned_img[1], dtype, width, height, rowb);
 }
 
+int mis_upload_pair2(mis_ctx* ctx, const void* img1, int width1, int height1, size_t row_stride1_bytes,
+                     const void* img2, int width2, int height2, size_t row_stride2_bytes, int dtype)
+{
+    int rc = check_pair_args(ctx, img1, img2, dtype, width1, height1, row_stride1_bytes);
+    if (rc) return rc;
+    rc = check_pair_args(ctx, img1, img2, dtype, width2, height2, row_stride2_bytes);
+    if (rc) return rc;
+    MIS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = width1 > width2 ? width1 : width2, H = height1 > height2 ? height1 : height2;
+    const size_t bpp = (size_t)mis_pixel_bytes(dtype), rowb = (size_t)W * bpp, bytes = rowb * H;
+    if (ctx->owned_img_bytes < bytes) {
+        if (ctx->img[0] == ctx->owned_img[0] || ctx->img[1] == ctx->owned_img[1]) {
+            drop_extra_bands(ctx);
+            ctx->img[0] = ctx->img[1] = nullptr;
+            ctx->pair_serial++;
+        }
+        for (int i = 0; i < 2; i++) {
+            if (ctx->owned_img[i]) { MIS_HIP(ctx, hipFree(ctx->owned_img[i])); ctx->owned_img[i] = nullptr; }
+        }
+        ctx->owned_img_bytes = 0;
+        for (int i = 0; i < 2; i++) MIS_HIP(ctx, hipMalloc(&ctx->owned_img[i], bytes));
+        ctx->owned_img_bytes = bytes;
+    }
+    const void* src[2] = { img1, img2 };
+    const int ws[2] = { width1, width2 }, hs[2] = { height1, height2 };
+    const size_t strides[2] = { row_stride1_bytes, row_stride2_bytes };
+    if (ctx->up_n) MIS_HIP(ctx, hipStreamSynchronize(ctx->up_stream));      // an earlier pair still on its way into these buffers
+    for (int i = 0; i < 2; i++) {
+        if (ws[i] != W || hs[i] != H) MIS_HIP(ctx, hipMemsetAsync(ctx->owned_img[i], 0, bytes, ctx->stream));
+        MIS_HIP(ctx, hipMemcpy2DAsync(ctx->owned_img[i], rowb, src[i], strides[i], (size_t)ws[i] * bpp, hs[i],
+                                      hipMemcpyHostToDevice, ctx->stream));
+    }
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return mis_bind_pair_device(ctx, ctx->owned_img[0], ctx->owned_img[1], dtype, W, H, rowb);
+}
+
 int mis_set_extra_bands_device(mis_ctx* ctx, int n_extra, const void* const* d_img1, const void* const* d_img2)
 {
     if (!ctx) return MIS_ERR_ARG;

@@ -32,13 +32,21 @@ int pow2_floor(int v) { int r = 0; while (v >>= 1) r++; return 1 << r; }
 int mis_disparity_map_with(const MisTileEval& eval, int image_width, int image_height, int min_size,
                            mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles)
 {
+    return mis_disparity_map_with2(eval, image_width, image_height, image_width, image_height, min_size, leaves, max_leaves, n_leaves, n_tiles);
+}
+
+int mis_disparity_map_with2(const MisTileEval& eval, int width1, int height1, int width2, int height2, int min_size,
+                            mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles)
+{
     if (!n_leaves || (max_leaves > 0 && !leaves) || min_size < 1) return MIS_ERR_ARG;
+    if (width1 < 1 || height1 < 1 || width2 < 1 || height2 < 1) return MIS_ERR_ARG;
     *n_leaves = 0;
     if (n_tiles) *n_tiles = 0;
     try {      // the containers below may throw (std::bad_alloc); nothing may leave the C ABI
-    const int src_width = image_width, src_height = image_height;       // image3.cpp:684-685
+    const int src_width = width2, src_height = height2;                 // the SECOND raster's size, image3.cpp:684-685
     std::vector<Node> level(1);
-    level[0].b1 = level[0].b2 = mis_rect{ 0, 0, image_width, image_height };   // image3.cpp:1001-1006
+    level[0].b1 = mis_rect{ 0, 0, width1, height1 };                     // image3.cpp:1001-1006
+    level[0].b2 = mis_rect{ 0, 0, width2, height2 };
     struct Leaf { mis_leaf l; std::vector<uint32_t> path; };
     std::vector<Leaf> out;
     int tiles = 0;
@@ -139,6 +147,20 @@ int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_s
             return mis_xcorr_tiles(ctx, r1, r2, n, w, h, out);
         };
         return mis_disparity_map_with(eval, image_width, image_height, min_size, leaves, max_leaves, n_leaves, n_tiles);
+    } catch (...) {
+        return MIS_ERR_STATE;
+    }
+}
+
+int mis_disparity_map2(mis_ctx* ctx, int width1, int height1, int width2, int height2, int min_size,
+                       mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles)
+{
+    if (!ctx) return MIS_ERR_ARG;
+    try {
+        const MisTileEval eval = [ctx](const mis_rect* r1, const mis_rect* r2, int n, int w, int h, mis_offset* out) {
+            return mis_xcorr_tiles(ctx, r1, r2, n, w, h, out);
+        };
+        return mis_disparity_map_with2(eval, width1, height1, width2, height2, min_size, leaves, max_leaves, n_leaves, n_tiles);
     } catch (...) {
         return MIS_ERR_STATE;
     }

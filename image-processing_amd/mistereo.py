@@ -58,7 +58,7 @@ EXPORTS = [
     "mis_group_upload_pair", "mis_group_xcorr_tiles", "mis_group_disparity_map", "mis_triangulate_disparity_rows_device",
     "mis_disparity_map", "mis_write_xyz", "mis_write_xyz_ex", "mis_rasterize_leaves", "mis_write_tiff_f32", "mis_load_camera_yaml",
     "mis_set_extra_bands_device", "mis_upload_extra_bands", "mis_masked_peak",
-    "mis_profile_enable", "mis_profile_read", "mis_version", "mis_pin_host", "mis_unpin_host", "mis_alloc_host", "mis_free_host",
+    "mis_profile_enable", "mis_profile_read", "mis_version", "mis_pin_host", "mis_unpin_host", "mis_alloc_host", "mis_free_host", "mis_upload_pair2", "mis_disparity_map2",
 ]
 
 _lib = None
@@ -93,6 +93,8 @@ def load_library():
         lib.mis_unpin_host.argtypes = [vp, vp]
         lib.mis_upload_pair.argtypes = [vp, vp, vp, i32, i32, i32, sz]
         lib.mis_bind_pair_device.argtypes = [vp, vp, vp, i32, i32, i32, sz]
+        lib.mis_upload_pair2.argtypes = [vp, vp, i32, i32, sz, vp, i32, i32, sz, i32]
+        lib.mis_disparity_map2.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]
         lib.mis_ncc_dense.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
         lib.mis_ncc_dense_device.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
         lib.mis_ncc_dense_rows.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
@@ -386,6 +388,19 @@ class Context:
         self._check(self._lib.mis_upload_pair(self._h, _np_ptr(img1), _np_ptr(img2), _dtype_code(img1.dtype),
                                               w, h, img1.strides[0]))
         self.shape = (h, w)
+        self.shapes2 = None
+        self._keep = None
+
+    def upload_pair2(self, img1, img2):
+        """Two rasters of different size (the reference only warns about them, image3.cpp:995-998): each is copied into
+        the top-left corner of a zeroed raster of the common size; disparity_map then keeps the two extents apart."""
+        img1, img2 = np.ascontiguousarray(img1), np.ascontiguousarray(img2)
+        if img1.dtype != img2.dtype or img1.ndim != 2 or img2.ndim != 2:
+            raise ValueError("image pair must be two 2-D rasters of one type")
+        self._check(self._lib.mis_upload_pair2(self._h, _np_ptr(img1), img1.shape[1], img1.shape[0], img1.strides[0],
+                                               _np_ptr(img2), img2.shape[1], img2.shape[0], img2.strides[0], _dtype_code(img1.dtype)))
+        self.shape = (max(img1.shape[0], img2.shape[0]), max(img1.shape[1], img2.shape[1]))
+        self.shapes2 = (img1.shape, img2.shape)
         self._keep = None
 
     def bind_pair_torch(self, t1, t2):
@@ -520,7 +535,12 @@ class Context:
         h, w = self.shape
         leaves = (Leaf * max_leaves)()
         n, nt = C.c_int(0), C.c_int(0)
-        self._check(self._lib.mis_disparity_map(self._h, w, h, min_size, leaves, max_leaves, C.byref(n), C.byref(nt)))
+        two = getattr(self, "shapes2", None)
+        if two is not None and self.shape == (max(two[0][0], two[1][0]), max(two[0][1], two[1][1])):
+            self._check(self._lib.mis_disparity_map2(self._h, two[0][1], two[0][0], two[1][1], two[1][0], min_size, leaves,
+                                                     max_leaves, C.byref(n), C.byref(nt)))
+        else:
+            self._check(self._lib.mis_disparity_map(self._h, w, h, min_size, leaves, max_leaves, C.byref(n), C.byref(nt)))
         if n.value > max_leaves:                    # same answer in a buffer that holds them all
             return self.disparity_map(min_size, n.value)
         recs = [(l.bbox1.minx, l.bbox1.miny, l.bbox1.width, l.bbox1.height, l.total_dx, l.total_dy,

@@ -267,6 +267,17 @@ typedef struct {
  * overlap" (image3.cpp:710-712) returns MIS_ERR_STATE. */
 int mis_disparity_map(mis_ctx* ctx, int image_width, int image_height, int min_size,
                       mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles);
+/* Two rasters of DIFFERENT size.  The reference only warns about them (image3.cpp:995-998): the first level
+ * correlates the whole of each raster, zero-padded to the larger width and height (image3.cpp:687-688, 322-328),
+ * and overlaps are clipped against the SECOND raster's extent (image3.cpp:684-685, 705-706).
+ * mis_upload_pair2 copies each raster into the top-left corner of a zeroed device raster of the common size
+ * max(w1,w2) x max(h1,h2) and binds that pair (every entry point then sees rasters of the common size whose
+ * pixels beyond a raster's own extent are zero, which is what the reference's zero-padded read delivers);
+ * mis_disparity_map2 is mis_disparity_map with the two extents kept apart. */
+int mis_upload_pair2(mis_ctx* ctx, const void* img1, int width1, int height1, size_t row_stride1_bytes,
+                     const void* img2, int width2, int height2, size_t row_stride2_bytes, int dtype);
+int mis_disparity_map2(mis_ctx* ctx, int width1, int height1, int width2, int height2, int min_size,
+                       mis_leaf* leaves, int max_leaves, int* n_leaves, int* n_tiles);
 
 /* Tile correlation over the group.  The tiles of one recursion level are independent (a child needs only its
  * parent's offset, image3.cpp:768-771) and reach anywhere in both rasters, so every device holds the whole pair

@@ -7,7 +7,8 @@
 
 typedef struct {
     const void* img1; const void* img2;
-    int dtype, width, height; size_t stride;
+    int dtype, width, height; size_t stride;      /* the second raster (image3.cpp:684-685 takes its size) */
+    int width1, height1; size_t stride1;          /* the first raster */
     int min_size, precision;
     orc_leaf* leaves; int max_leaves, n_leaves, n_calls, failed;
 } walk_t;
@@ -20,7 +21,7 @@ static void walk(walk_t* w, orc_rect bbox1, orc_rect bbox2)
     int height = bbox1.height > bbox2.height ? bbox1.height : bbox2.height;
 
     orc_offset off;
-    orc_find_offset(w->img1, w->width, w->height, w->stride, w->img2, w->width, w->height, w->stride,
+    orc_find_offset(w->img1, w->width1, w->height1, w->stride1, w->img2, w->width, w->height, w->stride,
                     w->dtype, bbox1, bbox2, width, height, w->precision, &off, NULL, NULL);
     w->n_calls++;
     float max = off.peak;
@@ -82,10 +83,20 @@ int orc_disparity_map(const void* img1, const void* img2, int dtype, int width, 
                       size_t stride_bytes, int min_size, int precision,
                       orc_leaf* leaves, int max_leaves, int* n_find_offset_calls)
 {
-    walk_t w = { img1, img2, dtype, width, height, stride_bytes, min_size, precision,
+    return orc_disparity_map2(img1, width, height, stride_bytes, img2, width, height, stride_bytes, dtype, min_size, precision,
+                              leaves, max_leaves, n_find_offset_calls);
+}
+
+/* Rasters of different size: the reference only warns (image3.cpp:995-998), starts from the whole of each raster
+ * (image3.cpp:1001-1006) and clips overlaps against the second raster's extent (image3.cpp:684-685). */
+int orc_disparity_map2(const void* img1, int width1, int height1, size_t stride1_bytes,
+                       const void* img2, int width2, int height2, size_t stride2_bytes, int dtype,
+                       int min_size, int precision, orc_leaf* leaves, int max_leaves, int* n_find_offset_calls)
+{
+    walk_t w = { img1, img2, dtype, width2, height2, stride2_bytes, width1, height1, stride1_bytes, min_size, precision,
                  leaves, max_leaves, 0, 0, 0 };
-    orc_rect full = { 0, 0, width, height };                     /* image3.cpp:1001-1006 */
-    walk(&w, full, full);
+    orc_rect full1 = { 0, 0, width1, height1 }, full2 = { 0, 0, width2, height2 };
+    walk(&w, full1, full2);
     if (n_find_offset_calls) *n_find_offset_calls = w.n_calls;
     return w.failed ? -1 : w.n_leaves;
 }

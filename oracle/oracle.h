@@ -98,6 +98,9 @@ typedef struct {
 int orc_disparity_map(const void* img1, const void* img2, int dtype, int width, int height,
                       size_t stride_bytes, int min_size, int precision,
                       orc_leaf* leaves, int max_leaves, int* n_find_offset_calls);
+int orc_disparity_map2(const void* img1, int width1, int height1, size_t stride1_bytes,
+                       const void* img2, int width2, int height2, size_t stride2_bytes, int dtype,
+                       int min_size, int precision, orc_leaf* leaves, int max_leaves, int* n_find_offset_calls);
 
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

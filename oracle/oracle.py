@@ -306,12 +306,12 @@ def triangulate_f(cam1, cam2, pts):
 def disparity_map(img1, img2, min_size=32, precision=0, max_leaves=1 << 16):
     img1 = np.ascontiguousarray(img1)
     img2 = np.ascontiguousarray(img2)
-    h, w = img1.shape
     leaves = (Leaf * max_leaves)()
     ncalls = C.c_int(0)
-    n = lib().orc_disparity_map(_ptr(img1), _ptr(img2), _dtype_code(img1), w, h,
-                                C.c_size_t(img1.strides[0]), min_size, precision,
-                                leaves, max_leaves, C.byref(ncalls))
+    # rasters of different size are allowed (image3.cpp:995-998 only warns)
+    n = lib().orc_disparity_map2(_ptr(img1), img1.shape[1], img1.shape[0], C.c_size_t(img1.strides[0]),
+                                 _ptr(img2), img2.shape[1], img2.shape[0], C.c_size_t(img2.strides[0]), _dtype_code(img1),
+                                 min_size, precision, leaves, max_leaves, C.byref(ncalls))
     if n < 0:
         raise RuntimeError("no overlap")
     recs = [(l.bbox1.minx, l.bbox1.miny, l.bbox1.width, l.bbox1.height, l.total_dx, l.total_dy,

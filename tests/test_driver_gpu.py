@@ -176,3 +176,28 @@ def test_recursion_equal_on_the_matrix_core_and_the_reference_ordered_gaussian(t
         for la, lb in zip(a[1], b[1]):
             assert la[:11] == lb[:11]                      # boxes, offsets, matched pixels, accept decision
             assert abs(la[11] - lb[11]) <= 1e-6
+
+
+@pytest.mark.parametrize("shape1,shape2,dx,dy", [((300, 420), (256, 400), 12, -7), ((256, 256), (300, 330), -9, 5), ((512, 400), (512, 512), 0, 3)])
+def test_rasters_of_different_size(ctx, shape1, shape2, dx, dy):
+    """The reference only warns when the two rasters differ in size (image3.cpp:995-998): the first level correlates
+    the whole of each, zero-padded to the larger extent (image3.cpp:687-688, 322-328), and overlaps are clipped against
+    the second raster (image3.cpp:684-685).  mis_upload_pair2 / mis_disparity_map2 against the oracle's walk on the two
+    rasters as they are."""
+    H, W = max(shape1[0], shape2[0]) + 60, max(shape1[1], shape2[1]) + 60
+    big = synth.texture(H, W, 4000 + shape1[0] + shape2[1])
+    img2 = np.ascontiguousarray(big[30:30 + shape2[0], 30:30 + shape2[1]])
+    img1 = np.ascontiguousarray(big[30 - dy:30 - dy + shape1[0], 30 - dx:30 - dx + shape1[1]])      # content moved by (dx, dy)
+    ctx.upload_pair2(img1, img2)
+    got, ntiles = ctx.disparity_map(min_size=32)
+    want, ncalls = oracle.disparity_map(img1, img2, min_size=32, precision=1)
+    assert ntiles == ncalls and len(got) == len(want) > 1
+    for g, w in zip(got, want):
+        assert g[:10] == w[:10]
+        assert abs(g[10] - w[10]) <= 1e-4 * max(abs(w[10]), 1e-3) + 1e-5
+    assert (got[0][4], got[0][5]) == (dx, dy)
+    # every matched pixel of the second raster lies inside it
+    assert all(0 <= g[8] < shape2[1] and 0 <= g[9] < shape2[0] for g in got)
+    ctx.upload_pair(img2, img2)                       # an equal-size pair afterwards takes the one-size path again
+    got, _ = ctx.disparity_map(min_size=64)
+    assert all((g[4], g[5]) == (0, 0) for g in got)

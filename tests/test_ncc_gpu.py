@@ -475,3 +475,40 @@ def test_page_locked_host_rasters(ctx):
     ctx.unpin_host(own)
     with pytest.raises(mistereo.MisError):
         ctx.unpin_host(own)                                  # not pinned any more
+
+
+def test_exact_ties_of_negative_scores_are_the_one_declared_deviation(ctx):
+    """The reference's rule is the FIRST maximum (image3.cpp:486-501): the lowest disparity among equal scores.  The
+    matrix-core kernel keeps it while the tied scores are positive; an exact tie between NEGATIVE best scores inside one
+    range of right columns may go to a higher disparity (the tag below a key's score bits orders the other way for
+    negative floats).  Such pixels have no correlating candidate at all and fail the 0.75 accept threshold of
+    image3.cpp:751, so no XYZ point changes.  Vertical stripes of period 7 under a 21-wide window, searched over
+    d = 1..6, tie all six candidates exactly at -1/6: the deviation is pinned here -- a pixel may differ from the
+    oracle's pick only by an exactly equal negative score, with an equal peak below the threshold -- and positive
+    ties keep the first maximum."""
+    h, w = 60, 300
+    col = np.where(np.arange(w + 40) % 7 == 0, 200, 40).astype(np.uint8)
+    base = np.repeat(col[None, :], h, axis=0)
+    left = np.ascontiguousarray(base[:, 20:20 + w])
+    right = left.copy()
+    ctx.upload_pair(left, right)
+    gpu = ctx.ncc_dense(21, 1, 6, want_idisp=True)
+    ora = oracle.ncc_dense(left, right, 21, 1, 6, want_volume=True)
+    valid = ora["idisp"] != -32768
+    assert np.array_equal(gpu["idisp"] == -32768, ~valid) and valid.sum() > 0
+    valid &= ~np.isnan(ora["volume"]).any(axis=2)            # pixels whose six candidates all fit the raster
+    vol = ora["volume"][valid]
+    assert np.all(vol.max(axis=1) < 0) and np.all(vol.max(axis=1) == vol.min(axis=1))      # six exactly equal negative scores
+    assert np.all(ora["idisp"][valid] == 1)                                                  # the reference's first maximum
+    gi = gpu["idisp"][valid].astype(int)
+    assert np.all((gi >= 1) & (gi <= 6))
+    deviating = int((gi != 1).sum())
+    print("exact ties of negative scores resolved to a higher disparity: %d of %d pixels (picks %s)" % (deviating, gi.size, np.unique(gi)))
+    assert np.array_equal(vol[np.arange(gi.size), gi - 1], vol[:, 0])                        # an exactly equal score, nothing else
+    assert np.allclose(gpu["peak"][valid], ora["peak"][valid], rtol=1e-6, atol=1e-7)
+    assert np.all(gpu["peak"][valid] < 0.75)
+    # the same stripes searched over d = 0..13 tie positively at d = 0, 7 (score 1): the first maximum, d = 0, is kept
+    gpu = ctx.ncc_dense(21, 0, 13, want_idisp=True)
+    ora = oracle.ncc_dense(left, right, 21, 0, 13)
+    valid = ora["idisp"] != -32768
+    assert np.all(ora["idisp"][valid] == 0) and np.all(gpu["idisp"][valid] == 0)
