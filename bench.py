@@ -59,6 +59,9 @@ def parse(argv=None):
                          "same ranks (reported under \"strips\"); force: run that leg at N=1 too (one strip, no transfers)")
     ap.add_argument("--second-peak", choices=["on", "off"], default="on",
                     help="at N=1 with extras: also time the step with the second-peak output (off for counter passes that sum per step)")
+    ap.add_argument("--cxx-gather", choices=["on", "off"], default="off",
+                    help="strips leg: afterwards gather the last result once more through libmistereo_rccl.so (the C++ RCCL "
+                         "gather of include/mi_stereo_rccl.h) and compare it with the torch.distributed one")
     ap.add_argument("--rehearse", action="store_true",
                     help="test only: no GPU and no library call -- the rank processes rendezvous over gloo and run the step loops of "
                          "both partitions with a stand-in for the correlation, to check the launcher, the gathers and the line's shape")
@@ -387,6 +390,28 @@ def strips_leg(args, rank, world, dev, ctx, stream, H, W, D, seed, full_frame, f
         cnt_all, t_tri = int(tsum[0].item()), float(tot[1].item())
     else:
         cnt_all = int(cnt)
+    cxx = None
+    if args.cxx_gather == "on":
+        # the same rows once more through the C++ gather (ncclSend / ncclRecv posted in one group on the library's stream)
+        import mistereo
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(mistereo.RcclGather.unique_id()), dtype=torch.uint8).to(dev)
+        if world > 1:
+            dist.broadcast(idt, 0)
+        rg = mistereo.RcclGather(bytes(idt.cpu().numpy().tobytes()), rank, world, dev.index)
+        full2 = [torch.zeros((H, W), dtype=torch.float32, device=dev) for _ in range(2)] if rank == 0 else None
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        rg.gather_rows(H, W, [own_d, own_p], job.local_row0, full2, stream.cuda_stream)
+        stream.synchronize()
+        t_c = time.perf_counter() - t_c
+        if rank == 0:
+            gd0, gp0 = job.result(max(args.steps - 1, 0))
+            cxx = {"equals_torch_gather_bits": bool(torch.equal(full2[0].view(torch.int32), gd0.view(torch.int32))
+                                                    and torch.equal(full2[1].view(torch.int32), gp0.view(torch.int32))),
+                   "ms": round(t_c * 1e3, 3)}
+        rg.close()
     if rank != 0:
         return None
     gd, gp = job.result(max(args.steps - 1, 0))
@@ -398,7 +423,7 @@ def strips_leg(args, rank, world, dev, ctx, stream, H, W, D, seed, full_frame, f
             "rows_per_rank": [n_ for _, n_ in partition.row_strips(H, world)],
             "halo_rows": args.window // 2, "gathered_equals_full_frame_bits": same,
             "matched_points_all_ranks": cnt_all, "matched_points_equal_full_frame": bool(cnt_all == full_frame_matched),
-            "triangulation_ms_per_rank_strip": round(t_tri * 1e3, 3),
+            "triangulation_ms_per_rank_strip": round(t_tri * 1e3, 3), "cxx_rccl_gather": cxx,
             "note": "rank 0's pair of the timed run, ONE pair sharded by row strips (each rank holds its strip plus halo rows only), "
                     "rows gathered into rank 0's rasters as grouped point-to-point transfers overlapped with the next step"}
 

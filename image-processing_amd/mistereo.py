@@ -62,6 +62,72 @@ EXPORTS = [
 ]
 
 _lib = None
+_rccl_lib = None
+RCCL_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmistereo_rccl.so")
+RCCL_EXPORTS = ["mis_rccl_unique_id", "mis_rccl_comm_init", "mis_rccl_comm_destroy", "mis_rccl_row_strip", "mis_rccl_gather_rows"]
+
+
+def load_rccl_library():
+    """libmistereo_rccl.so (include/mi_stereo_rccl.h): the row gather over RCCL for one process per GPU."""
+    global _rccl_lib
+    if _rccl_lib is None:
+        if not os.path.exists(RCCL_LIB_PATH):
+            raise ImportError("libmistereo_rccl.so is missing (%s): build it with `make -C image-processing_amd`" % RCCL_LIB_PATH)
+        try:
+            import torch  # noqa: F401  (its ROCm libraries first, see load_library)
+        except ImportError:
+            pass
+        lib = C.CDLL(RCCL_LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
+        lib.mis_rccl_unique_id.argtypes = [C.c_char_p]
+        lib.mis_rccl_comm_init.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+        lib.mis_rccl_comm_destroy.argtypes = [vp]
+        lib.mis_rccl_row_strip.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+        lib.mis_rccl_row_strip.restype = None
+        lib.mis_rccl_gather_rows.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(vp), i32, C.POINTER(vp), vp]
+        _rccl_lib = lib
+    return _rccl_lib
+
+
+class RcclGather:
+    """One RCCL communicator over the ranks of a job and the gather of result rows to rank 0 through it.
+    id_bytes: rank 0 calls RcclGather.unique_id() and hands the 128 bytes to the other ranks."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = load_rccl_library().mis_rccl_unique_id(buf)
+        if rc:
+            raise MisError(rc, "mis_rccl_unique_id failed")
+        return buf.raw
+
+    def __init__(self, id_bytes, rank, world, device):
+        self._lib = load_rccl_library()
+        self.rank, self.world = rank, world
+        self._comm = C.c_void_p()
+        rc = self._lib.mis_rccl_comm_init(id_bytes, rank, world, device, C.byref(self._comm))
+        if rc:
+            raise MisError(rc, "mis_rccl_comm_init failed (rank %d of %d)" % (rank, world))
+
+    def row_strip(self, height, rank=None):
+        r0, n = C.c_int(0), C.c_int(0)
+        self._lib.mis_rccl_row_strip(height, self.world, self.rank if rank is None else rank, C.byref(r0), C.byref(n))
+        return r0.value, n.value
+
+    def gather_rows(self, height, width, strips, strip_row0, full, stream_ptr):
+        """strips: this rank's CUDA float32 rasters; full: rank 0's frame rasters (None elsewhere)."""
+        n = len(strips)
+        src = (C.c_void_p * n)(*[t.data_ptr() for t in strips])
+        dst = (C.c_void_p * n)(*[t.data_ptr() for t in full]) if full is not None else None
+        rc = self._lib.mis_rccl_gather_rows(self._comm, self.rank, self.world, height, width, n, src, strip_row0, dst,
+                                            C.c_void_p(stream_ptr))
+        if rc:
+            raise MisError(rc, "mis_rccl_gather_rows failed (rank %d of %d)" % (self.rank, self.world))
+
+    def close(self):
+        if self._comm:
+            self._lib.mis_rccl_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
 
 
 def load_library():

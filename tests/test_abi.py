@@ -55,3 +55,23 @@ def test_product_path_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in text and "import oracle" not in text and "oracle/" not in text, f
+
+
+def test_rccl_gather_library_loads_and_splits_rows_like_the_python_partition():
+    """libmistereo_rccl.so exports what include/mi_stereo_rccl.h declares; its row split (pure host arithmetic) is the
+    one partition.row_strips and the library's own groups use."""
+    import re
+    import ctypes as C
+    import partition
+    lib = mistereo.load_rccl_library()
+    header = open(os.path.join(ROOT, "include", "mi_stereo_rccl.h")).read()
+    declared = sorted(set(re.findall(r"\b(mis_rccl_\w+)\s*\(", header)))
+    assert declared == sorted(mistereo.RCCL_EXPORTS)
+    for name in declared:
+        getattr(lib, name)
+    for h, world in ((8192, 8), (100, 3), (5, 8), (16384, 2), (7, 1)):
+        want = partition.row_strips(h, world)
+        for rank in range(world):
+            r0, n = C.c_int(-1), C.c_int(-1)
+            lib.mis_rccl_row_strip(h, world, rank, C.byref(r0), C.byref(n))
+            assert (r0.value, n.value) == tuple(want[rank])

@@ -130,3 +130,28 @@ def test_group_argument_errors():
             g.ncc_dense(a, a, 4, -1, 1)      # even window
     finally:
         g.close()
+
+
+def test_rccl_gather_library_on_a_world_of_one():
+    """libmistereo_rccl.so (include/mi_stereo_rccl.h): a communicator over RCCL and the gather of result rows into
+    rank 0's frame rasters.  One GPU here, so the world is one rank: the communicator is a real RCCL one, the gather
+    is rank 0's own rows moved from a strip raster (with halo rows above) into place; nothing is received.  Several
+    ranks need several GPUs: never run on this build's test box (multi-rank part unmeasured)."""
+    import torch
+    h, w, halo = 37, 53, 10
+    g = mistereo.RcclGather(mistereo.RcclGather.unique_id(), 0, 1, 0)
+    try:
+        assert g.row_strip(h) == (0, h)
+        strips = [torch.rand((halo + h, w), device="cuda"), torch.rand((halo + h, w), device="cuda")]
+        full = [torch.zeros((h, w), device="cuda"), torch.zeros((h, w), device="cuda")]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        g.gather_rows(h, w, strips, halo, full, s.cuda_stream)
+        s.synchronize()
+        assert torch.equal(full[0], strips[0][halo:]) and torch.equal(full[1], strips[1][halo:])
+        # rows already in place (rank 0 computed into the frame rasters): nothing moves
+        g.gather_rows(h, w, full, 0, full, s.cuda_stream)
+        s.synchronize()
+        assert torch.equal(full[0], strips[0][halo:])
+    finally:
+        g.close()
