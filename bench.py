@@ -892,6 +892,24 @@ def main():
                                      "gpx_disp_per_s": round(float(H) * W * nd / ms2 / 1e6, 1),
                                      "note": "same pair and search with the peak2 raster requested; parity of peak2 is covered by the GPU tests"}
             del pk2
+        if world == 1 and args.extras == "on" and args.second_peak == "on" and args.window <= 21:
+            # the same pair and search under a 31 x 31 window: from 23 x 23 on only the window sums slide on the matrix
+            # cores and the mean correction's integer part is one more vector instruction per score
+            d31, p31 = torch.empty_like(dp), torch.empty_like(pk)      # (dp / pk stay the plain step's result)
+            with torch.cuda.stream(stream):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                for i in range(4):
+                    if i == 1:
+                        e[0].record(stream)
+                    ctx.bind_pair_torch(left, right)
+                    ctx.ncc_dense_torch(31, -D, D, d31, p31)
+                e[1].record(stream)
+            stream.synchronize()
+            del d31, p31
+            ms31 = e[0].elapsed_time(e[1]) / 3
+            result["window_31"] = {"ms_per_step": round(ms31, 3), "vs_plain_step": round(ms31 / (dt / max(args.steps, 1) * 1e3), 3),
+                                   "gpx_disp_per_s": round(float(H) * W * nd / ms31 / 1e6, 1),
+                                   "note": "same pair and search, 31x31 window (matrix-core kernels; parity covered by the GPU tests)"}
         if world == 1 and args.extras == "on":
             result["path_f"] = bench_path_f(ctx, stream, dev, left_h, cpu=args.cpu_rows > 0)
             result["ncc16"] = bench_ncc16(ctx, stream, dev, cpu=args.cpu_rows > 0)
