@@ -362,6 +362,8 @@ int mis_upload_pair(mis_ctx* ctx, const void* img1, const void* img2, int dtype,
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     size_t rowb = (size_t)width * mis_pixel_bytes(dtype);
     size_t bytes = rowb * height;
+    // an earlier pair still on its way into the context's rasters: it must have landed before they are rewritten or freed
+    if (ctx->up_n) { MIS_HIP(ctx, hipStreamSynchronize(ctx->up_stream)); ctx->up_n = 0; }
     if (ctx->owned_img_bytes < bytes) {
         // the bound pair may be these very buffers: unbind before they are freed, so that a failed
         // allocation below leaves the context without a pair instead of with dangling pointers
@@ -425,6 +427,7 @@ int mis_upload_pair2(mis_ctx* ctx, const void* img1, int width1, int height1, si
     MIS_HIP(ctx, hipSetDevice(ctx->device));
     const int W = width1 > width2 ? width1 : width2, H = height1 > height2 ? height1 : height2;
     const size_t bpp = (size_t)mis_pixel_bytes(dtype), rowb = (size_t)W * bpp, bytes = rowb * H;
+    if (ctx->up_n) { MIS_HIP(ctx, hipStreamSynchronize(ctx->up_stream)); ctx->up_n = 0; }   // an earlier pair still on its way into these rasters
     if (ctx->owned_img_bytes < bytes) {
         if (ctx->img[0] == ctx->owned_img[0] || ctx->img[1] == ctx->owned_img[1]) {
             drop_extra_bands(ctx);
@@ -441,7 +444,6 @@ int mis_upload_pair2(mis_ctx* ctx, const void* img1, int width1, int height1, si
     const void* src[2] = { img1, img2 };
     const int ws[2] = { width1, width2 }, hs[2] = { height1, height2 };
     const size_t strides[2] = { row_stride1_bytes, row_stride2_bytes };
-    if (ctx->up_n) MIS_HIP(ctx, hipStreamSynchronize(ctx->up_stream));      // an earlier pair still on its way into these buffers
     for (int i = 0; i < 2; i++) {
         if (ws[i] != W || hs[i] != H) MIS_HIP(ctx, hipMemsetAsync(ctx->owned_img[i], 0, bytes, ctx->stream));
         MIS_HIP(ctx, hipMemcpy2DAsync(ctx->owned_img[i], rowb, src[i], strides[i], (size_t)ws[i] * bpp, hs[i],

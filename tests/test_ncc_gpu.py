@@ -455,6 +455,20 @@ def test_page_locked_host_rasters(ctx):
             ctx.ncc_dense_rows(15, -40, 24, 100, 57, disp, peak)         # a strip: the other rows keep their contents
             assert np.array_equal(disp[100:157].view(np.uint32), want["disp"][100:157].view(np.uint32))
             assert (disp[:100] == 777.0).all() and (disp[157:] == 777.0).all()
+        # uploads in a row: a pair still on its way (the page-locked upload returns at once) is not overtaken by the next
+        # one, page-locked or pageable
+        other = synth.shift_right_image(left, 7, fill_seed=3)
+        ctx.upload_pair(left, other)
+        want7 = ctx.ncc_dense(15, -40, 24, want_idisp=False)["disp"]
+        pr2 = ctx.alloc_host((h, w), np.uint8)
+        pr2[:] = other
+        ctx.upload_pair(pl, pr); ctx.upload_pair(pl, pr2)
+        ctx.ncc_dense_rows(15, -40, 24, 0, h, disp, peak)
+        assert np.array_equal(disp.view(np.uint32), want7.view(np.uint32))
+        ctx.upload_pair(pl, pr2); ctx.upload_pair(left, right)
+        ctx.ncc_dense_rows(15, -40, 24, 0, h, disp, peak)
+        assert np.array_equal(disp.view(np.uint32), want["disp"].view(np.uint32))
+        ctx.free_host(pr2)
         # a page-locked output beside a pageable one: the staged path serves both
         pageable = np.full((h, w), 5.0, np.float32)
         ctx.ncc_dense_rows(15, -40, 24, 0, h, disp, pageable)
