@@ -351,14 +351,15 @@ class Group:
                  l.u1, l.v1, l.u2, l.v2, l.peak) for l in leaves[:min(n.value, max_leaves)]]
         return recs, nt.value
 
-    def ncc_dense(self, left, right, window, dmin, dmax, want_idisp=True, want_peak2=False):
-        """Dense NCC of a host pair, row strips over the group's devices; same result as Context.ncc_dense."""
+    def ncc_dense(self, left, right, window, dmin, dmax, want_idisp=True, want_peak2=False, out=None):
+        """Dense NCC of a host pair, row strips over the group's devices; same result as Context.ncc_dense.
+        out: (disp, peak) float32 rasters of the caller's (page-locked ones are written by DMA)."""
         left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
         if left.shape != right.shape or left.dtype != right.dtype:
             raise ValueError("the two rasters must have one shape and type")
         h, w = left.shape
-        disp = np.empty((h, w), np.float32)
-        peak = np.empty((h, w), np.float32)
+        disp = np.empty((h, w), np.float32) if out is None else out[0]
+        peak = np.empty((h, w), np.float32) if out is None else out[1]
         idisp = np.empty((h, w), np.int16) if want_idisp else None
         peak2 = np.empty((h, w), np.float32) if want_peak2 else None
         rc = self._lib.mis_group_ncc_dense(self._h, _np_ptr(left), _np_ptr(right), _dtype_code(left.dtype), w, h,

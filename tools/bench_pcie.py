@@ -29,6 +29,16 @@ for it in range(4):
     print("page-locked: upload %.1f ms, ncc_dense with host outputs %.1f ms, total %.1f ms -> %.1f Gpx*disp/s" % (
         (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3, size * size * (2 * D + 1) / (t2 - t0) / 1e9), flush=True)
 assert np.array_equal(disp.view(np.uint32), out["disp"].view(np.uint32)) and np.array_equal(peak.view(np.uint32), out["peak"].view(np.uint32))
+# ... and through a group on page-locked rasters (every slot is GPU 0 here: its host threads share one device and one link)
+for slots in (1, 2):
+    g = mistereo.Group([0] * slots)
+    for it in range(3):
+        t0 = time.perf_counter()
+        g.ncc_dense(pl, pr, win, -D, D, want_idisp=False, out=(disp, peak))
+        t1 = time.perf_counter()
+    print("page-locked, group of %d slot(s) on one GPU: %.1f ms -> %.1f Gpx*disp/s" % (slots, (t1 - t0) * 1e3, size * size * (2 * D + 1) / (t1 - t0) / 1e9), flush=True)
+    assert np.array_equal(disp.view(np.uint32), out["disp"].view(np.uint32))
+    g.close()
 for a in (pl, pr, disp, peak):
     ctx.free_host(a)
 # the same through a group (one process over several GPUs; here every slot is GPU 0): strips in parallel host threads
