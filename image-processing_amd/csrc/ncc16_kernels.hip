@@ -552,6 +552,10 @@ static int ncc16_prepare(mis_ctx* ctx, int window, int need_lo, int need_hi)
     w->pitch = pitch; w->rows = H;
     w->pair_serial = 0;               // the cache claims nothing until every launch below has been accepted
     hipStream_t s = ctx->stream;
+    {   // a pair still on its way from page-locked host rasters: the rows the table kernels read must have arrived
+        int rcu = mis_wait_upload(ctx, need_hi + r < H ? need_hi + r : H, s);
+        if (rcu) return rcu;
+    }
     const size_t stride_px = ctx->stride / 2;
     const dim3 block(256);
     for (int k = 0; k < nparts; k++) {

@@ -1104,6 +1104,13 @@ static int ncc_prepare(mis_ctx* ctx, int window, bool use_side, int need_lo, int
         if (rc) return rc;
         sv = w->side;
     }
+    {   // a pair still on its way from page-locked host rasters: the rows the table kernels read (whole bands of rows
+        // plus the window's rows below them) must have arrived, on both streams (the side stream forked earlier)
+        const int upto = need_hi + r + 4 < H ? need_hi + r + 4 : H;
+        int rcu = mis_wait_upload(ctx, upto, s);
+        if (!rcu && sv != s) rcu = mis_wait_upload(ctx, upto, sv);
+        if (rcu) return rcu;
+    }
     if (ctx->dtype != MIS_U8)
         return mis_fail(ctx, MIS_ERR_UNSUPPORTED, "dense NCC: only 8-bit rasters are supported by this build");
     const uint8_t* pl = (const uint8_t*)ctx->img[0];
@@ -1259,10 +1266,6 @@ static int ncc_run(mis_ctx* ctx, int window, int dmin, int dmax, int row0, int n
     if (nrows == 0) return MIS_OK;
 
     mis_prof_mark(ctx);
-    {   // a pair still on its way from page-locked host rasters: the rows this call reads must have arrived
-        int rcu = mis_wait_upload(ctx, (row0 + nrows + r < H) ? row0 + nrows + r : H, ctx->stream);
-        if (rcu) return rcu;
-    }
     // the 8-bit path runs its small kernels on a second stream
     const bool fast = (ctx->dtype == MIS_U8 && W >= window && H >= window);
     if (fast && !ctx->ncc) ctx->ncc = new NccWs();

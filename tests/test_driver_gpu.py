@@ -201,3 +201,23 @@ def test_rasters_of_different_size(ctx, shape1, shape2, dx, dy):
     ctx.upload_pair(img2, img2)                       # an equal-size pair afterwards takes the one-size path again
     got, _ = ctx.disparity_map(min_size=64)
     assert all((g[4], g[5]) == (0, 0) for g in got)
+
+
+def test_rasters_of_different_size_read_as_zero_beyond_their_extent(ctx):
+    """mis_upload_pair2 binds both rasters at the common size with zeros beyond each raster's own extent: every entry
+    point then answers as for the explicitly zero-padded pair (dense NCC bit for bit, tile correlation likewise)."""
+    a = synth.texture(150, 260, 61)
+    b = synth.texture(190, 220, 62)
+    H, W = 190, 260
+    pa = np.zeros((H, W), np.uint8); pa[:150, :260] = a
+    pb = np.zeros((H, W), np.uint8); pb[:190, :220] = b
+    ctx.upload_pair(pa, pb)
+    want = ctx.ncc_dense(9, -12, 12)
+    wo = ctx.find_offsets([(0, 0, 128, 128), (100, 40, 64, 64)], [(0, 0, 128, 128), (90, 50, 64, 64)], 128, 128)
+    ctx.upload_pair2(a, b)
+    got = ctx.ncc_dense(9, -12, 12)
+    for k in ("disp", "peak"):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+    assert np.array_equal(got["idisp"], want["idisp"])
+    go = ctx.find_offsets([(0, 0, 128, 128), (100, 40, 64, 64)], [(0, 0, 128, 128), (90, 50, 64, 64)], 128, 128)
+    assert np.array_equal(np.asarray(go), np.asarray(wo))

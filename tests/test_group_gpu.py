@@ -155,3 +155,28 @@ def test_rccl_gather_library_on_a_world_of_one():
         assert torch.equal(full[0], strips[0][halo:])
     finally:
         g.close()
+
+
+def test_group_on_page_locked_rasters(ctx):
+    """Page-locked rasters through a group: every slot's strip travels by DMA (the upload returns while it is on its way)
+    and its rows are copied straight into the caller's rasters; same bits as one device on pageable memory."""
+    h, w = 260, 700
+    left, right = _pair(h, w, np.uint16, 91, 13)
+    ctx.upload_pair(left, right)
+    one = ctx.ncc_dense(31, -50, 50, want_idisp=False)
+    pl, pr = ctx.alloc_host((h, w), np.uint16), ctx.alloc_host((h, w), np.uint16)
+    disp, peak = ctx.alloc_host((h, w), np.float32), ctx.alloc_host((h, w), np.float32)
+    try:
+        pl[:] = left; pr[:] = right
+        g = mistereo.Group([0, 0, 0])
+        try:
+            for rep in range(2):
+                disp[:] = 0; peak[:] = 0
+                g.ncc_dense(pl, pr, 31, -50, 50, want_idisp=False, out=(disp, peak))
+                assert np.array_equal(disp.view(np.uint32), one["disp"].view(np.uint32))
+                assert np.array_equal(peak.view(np.uint32), one["peak"].view(np.uint32))
+        finally:
+            g.close()
+    finally:
+        for a in (pl, pr, disp, peak):
+            ctx.free_host(a)
