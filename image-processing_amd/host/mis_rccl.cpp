@@ -85,4 +85,30 @@ int mis_rccl_gather_rows(void* comm, int rank, int world, int height, int width,
     return (r == ncclSuccess && e == ncclSuccess) ? MIS_RCCL_OK : MIS_RCCL_ERR_COMM;
 }
 
+int mis_rccl_gather_frames(void* comm, int rank, int world, size_t n_floats, int n_rasters,
+                           const float* const* d_src, float* const* d_dst, void* hip_stream)
+{
+    if (!comm || world < 1 || rank < 0 || rank >= world || n_floats < 1 || n_rasters < 1 || !d_src) return MIS_RCCL_ERR_ARG;
+    if (rank == 0 && !d_dst) return MIS_RCCL_ERR_ARG;
+    const ncclComm_t c = (ncclComm_t)comm;
+    const hipStream_t s = (hipStream_t)hip_stream;
+    if (rank == 0) {
+        for (int i = 0; i < n_rasters; i++)
+            if (d_dst[i] != d_src[i] &&
+                hipMemcpyAsync(d_dst[i], d_src[i], n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return MIS_RCCL_ERR_DEVICE;
+    }
+    if (world == 1) return MIS_RCCL_OK;
+    ncclResult_t r = ncclGroupStart();
+    if (rank == 0) {
+        for (int k = 1; k < world && r == ncclSuccess; k++)
+            for (int i = 0; i < n_rasters && r == ncclSuccess; i++)
+                r = ncclRecv(d_dst[(size_t)k * n_rasters + i], n_floats, ncclFloat, k, c, s);
+    } else {
+        for (int i = 0; i < n_rasters && r == ncclSuccess; i++) r = ncclSend(d_src[i], n_floats, ncclFloat, 0, c, s);
+    }
+    const ncclResult_t e = ncclGroupEnd();
+    return (r == ncclSuccess && e == ncclSuccess) ? MIS_RCCL_OK : MIS_RCCL_ERR_COMM;
+}
+
 }  // extern "C"

@@ -64,7 +64,8 @@ EXPORTS = [
 _lib = None
 _rccl_lib = None
 RCCL_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmistereo_rccl.so")
-RCCL_EXPORTS = ["mis_rccl_unique_id", "mis_rccl_comm_init", "mis_rccl_comm_destroy", "mis_rccl_row_strip", "mis_rccl_gather_rows"]
+RCCL_EXPORTS = ["mis_rccl_unique_id", "mis_rccl_comm_init", "mis_rccl_comm_destroy", "mis_rccl_row_strip", "mis_rccl_gather_rows",
+                "mis_rccl_gather_frames"]
 
 
 def load_rccl_library():
@@ -85,6 +86,7 @@ def load_rccl_library():
         lib.mis_rccl_row_strip.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         lib.mis_rccl_row_strip.restype = None
         lib.mis_rccl_gather_rows.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(vp), i32, C.POINTER(vp), vp]
+        lib.mis_rccl_gather_frames.argtypes = [vp, i32, i32, C.c_size_t, i32, C.POINTER(vp), C.POINTER(vp), vp]
         _rccl_lib = lib
     return _rccl_lib
 
@@ -123,6 +125,18 @@ class RcclGather:
                                             C.c_void_p(stream_ptr))
         if rc:
             raise MisError(rc, "mis_rccl_gather_rows failed (rank %d of %d)" % (self.rank, self.world))
+
+    def gather_frames(self, srcs, dsts, stream_ptr):
+        """srcs: this rank's CUDA float32 rasters; dsts (rank 0): [rank][raster] tensors of the same size."""
+        n = len(srcs)
+        src = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+        dst = None
+        if dsts is not None:
+            flat = [t.data_ptr() for per_rank in dsts for t in per_rank]
+            dst = (C.c_void_p * len(flat))(*flat)
+        rc = self._lib.mis_rccl_gather_frames(self._comm, self.rank, self.world, srcs[0].numel(), n, src, dst, C.c_void_p(stream_ptr))
+        if rc:
+            raise MisError(rc, "mis_rccl_gather_frames failed (rank %d of %d)" % (self.rank, self.world))
 
     def close(self):
         if self._comm:

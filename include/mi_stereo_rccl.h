@@ -37,6 +37,13 @@ void mis_rccl_row_strip(int height, int world, int rank, int* row0, int* nrows);
 int mis_rccl_gather_rows(void* comm, int rank, int world, int height, int width, int n_rasters,
                          const float* const* d_strip, int strip_row0, float* const* d_full, void* hip_stream);
 
+/* Whole pairs per rank (a batch of frames): gathers every rank's n_rasters float rasters of n_floats values each to
+ * rank 0.  d_src[i]: this rank's raster i; d_dst (rank 0 only): world * n_rasters device pointers, d_dst[k * n_rasters + i]
+ * receives raster i of rank k (rank 0's own are copied unless d_dst[i] == d_src[i]).  One group on hip_stream;
+ * collective over all ranks. */
+int mis_rccl_gather_frames(void* comm, int rank, int world, size_t n_floats, int n_rasters,
+                           const float* const* d_src, float* const* d_dst, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,6 +153,11 @@ def test_rccl_gather_library_on_a_world_of_one():
         g.gather_rows(h, w, full, 0, full, s.cuda_stream)
         s.synchronize()
         assert torch.equal(full[0], strips[0][halo:])
+        # whole rasters per rank (the frames partition)
+        dst = [[torch.zeros((h, w), device="cuda"), torch.zeros((h, w), device="cuda")]]
+        g.gather_frames(full, dst, s.cuda_stream)
+        s.synchronize()
+        assert torch.equal(dst[0][0], full[0]) and torch.equal(dst[0][1], full[1])
     finally:
         g.close()
 
