@@ -1,7 +1,7 @@
 """Randomised parity stress of the dense NCC (8-bit: the matrix-core kernels for every window, the mean correction inside
 the products up to 21 x 21 and on the vector unit beyond) against the CPU oracle, beyond the cases the test-suite pins:
-   python tools/stress_ncc.py [cases] [seed]
-Every case: random frame shape, window, search range, shift, optional row strip or second-peak output; prints a
+   python tools/stress_ncc.py [cases] [seed] [u8|u16|mix]
+(16-bit pairs take the integer kernels of csrc/ncc16_kernels.hip: full-range textures, saturated patches.)  Every case: random frame shape, window, search range, shift, optional row strip or second-peak output; prints a
 line per failure."""
 import os, sys
 R0 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,17 @@ from ncc_util import compare_ncc, flat_mask
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+pixels = sys.argv[3] if len(sys.argv) > 3 else "u8"
+assert pixels in ("u8", "u16", "mix")
+
+
+def texture16(h, w, seed):
+    """16-bit texture over the full range (not only multiples of 257)"""
+    r = np.random.default_rng(seed)
+    t = synth.texture(h, w, seed, np.uint16).astype(np.int64) + r.integers(-120, 121, (h, w))
+    return np.clip(t, 0, 65535).astype(np.uint16)
+
+
 ctx = mistereo.Context(0)
 bad = 0
 for k in range(cases):
@@ -24,20 +35,26 @@ for k in range(cases):
     w = int(rng.integers(max(window, 20), 420))
     if rng.random() < 0.2:
         w = int(rng.choice([64, 65, 127, 128, 129, 192, 256])) + 2 * (window // 2)
-    left = synth.texture(h, w, 7000 + k)
+    wide = pixels == "u16" or (pixels == "mix" and rng.random() < 0.5)
+    left = texture16(h, w, 7000 + k) if wide else synth.texture(h, w, 7000 + k)
+    top = 65535 if wide else 255
     shift = int(rng.integers(dmin, dmax + 1))
     right = synth.shift_right_image(left, shift, fill_seed=k)
     if rng.random() < 0.25:
-        left[h // 4: h // 2, w // 5: w // 2] = int(rng.integers(0, 256))      # flat patch
+        left[h // 4: h // 2, w // 5: w // 2] = int(rng.integers(0, top + 1))  # flat patch
     if rng.random() < 0.15:
-        right = (rng.integers(0, 2, right.shape) * 255).astype(np.uint8)      # extreme contrast
+        right = (rng.integers(0, 2, right.shape) * top).astype(left.dtype)    # extreme contrast
     want2 = False
     try:
         ctx.upload_pair(left, right)
         if rng.random() < 0.4 and h > window + 3:
             # a row strip computed on its own must equal the oracle's rows
             row0 = int(rng.integers(0, h - 1)); nrows = int(rng.integers(1, h - row0 + 1))
-            tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+            if wide:
+                tl = torch.from_numpy(left.view(np.int16)).cuda().view(torch.uint16)
+                tr = torch.from_numpy(right.view(np.int16)).cuda().view(torch.uint16)
+            else:
+                tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
             ctx.bind_pair_torch(tl, tr)
             d = torch.full((h, w), -7.0, device="cuda"); p = torch.full((h, w), -7.0, device="cuda")
             i = torch.full((h, w), -7, device="cuda", dtype=torch.int16)
@@ -74,7 +91,7 @@ for k in range(cases):
                 "%d argmax differences (%d exact ties of negative scores), largest score gap %g" % (len(ys), declared.sum(), gap.max())
     except AssertionError as e:
         bad += 1
-        print("FAIL case", k, dict(window=window, dmin=dmin, dmax=dmax, h=h, w=w, shift=shift), str(e)[:200], flush=True)
+        print("FAIL case", k, dict(wide=wide, window=window, dmin=dmin, dmax=dmax, h=h, w=w, shift=shift), str(e)[:200], flush=True)
     if k % 50 == 49:
         print("...", k + 1, "cases,", bad, "failures", flush=True)
 print("done:", cases, "cases,", bad, "failures")
