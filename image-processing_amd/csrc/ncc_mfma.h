@@ -87,6 +87,10 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     static_assert(32 * (2 * R + 1) * 128 * 128 < (1 << 24), "partial sums of S: window, entering and leaving row");
     static_assert(NB == 2, "the half-wave merge pairs two column blocks");
     static_assert(16 * T <= 64, "register tags are inline constants");
+    static_assert(T == 3, "the scored rows place their memory operations by tile and column block");
+    // the scored rows spread their loads and the key store over the row (see fetch_part); with four products per tile the
+    // kernels have no registers to spare for the longer live ranges and keep the burst at the top of the row
+    constexpr bool SPREAD = KS <= 3;
     static_assert(!CORR || 8 * KS - 2 > 2 * R, "two spare taps behind the window");
     static_assert(8 * KS > 2 * R, "the products cover the window's taps");
     __shared__ __attribute__((aligned(16))) float sR[4 * CS];
@@ -177,22 +181,32 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     // rows are clamped into the band instead: the statistics fetched for warm-up rows and after the last row
     // are finite and never scored
     const int ylast = yb1 - 1 + R;
-    auto fetch = [&](int ynew) {
+    // The ten loads of a row in four parts -- 0: right rows, 1: left rows, 2: right statistics, 3: left statistics.  The scored
+    // rows issue them (and the key store) one part per scoring block instead of as one burst at the top of the row: a burst
+    // waits for room in the CU's memory pipeline with nothing else to issue (0.4 ms of the 21 x 21 frame).
+    auto fetch_part = [&](int part, int ynew) {
         const int yn = min(ynew, ylast), yo = min(max(yn - R, yb0), yb1 - 1);
-        const uint32_t* rp = gRpack + (size_t)yn * P;
-        const uint32_t* lp = gLpack + (size_t)yn * P;
-        const float* sp = gRsr + (size_t)yo * P;
-        const float* ip = gRir + (size_t)yo * P;
-        const float* cp = gNegc + (size_t)yo * P;
-        const float* gp = gNegg + (size_t)yo * P;
-        __builtin_memcpy(&fr[0], rp + ccR0, 16);
-        __builtin_memcpy(&fr[1], rp + ccR1, 16);
-        __builtin_memcpy(&fl[0], lp + colL[0], 16);
-        __builtin_memcpy(&fl[1], lp + colL[1], 16);
-        __builtin_memcpy(&fsr, sp + ccT, 16);
-        __builtin_memcpy(&fir, ip + ccT, 16);
+        if (part == 0) {
+            const uint32_t* rp = gRpack + (size_t)yn * P;
+            __builtin_memcpy(&fr[0], rp + ccR0, 16);
+            __builtin_memcpy(&fr[1], rp + ccR1, 16);
+        } else if (part == 1) {
+            const uint32_t* lp = gLpack + (size_t)yn * P;
+            __builtin_memcpy(&fl[0], lp + colL[0], 16);
+            __builtin_memcpy(&fl[1], lp + colL[1], 16);
+        } else if (part == 2) {
+            __builtin_memcpy(&fsr, gRsr + (size_t)yo * P + ccT, 16);
+            __builtin_memcpy(&fir, gRir + (size_t)yo * P + ccT, 16);
+        } else {
+            const float* cp = gNegc + (size_t)yo * P;
+            const float* gp = gNegg + (size_t)yo * P;
 #pragma unroll
-        for (int c = 0; c < NB; c++) { fnc[c] = cp[nlcol + 32 * c]; fng[c] = gp[nlcol + 32 * c]; }
+            for (int c = 0; c < NB; c++) { fnc[c] = cp[nlcol + 32 * c]; fng[c] = gp[nlcol + 32 * c]; }
+        }
+    };
+    auto fetch = [&](int ynew) {
+#pragma unroll
+        for (int part = 0; part < 4; part++) fetch_part(part, ynew);
     };
     const uint32_t qnan = 0x7FC00000u;
     // row: the output row the statistics belong to (its parity picks the slot of the (s1, s0) pairs)
@@ -296,7 +310,16 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     };
 
     // the half-waves' keys of a row -> one key per left column -> key plane
-    auto emit = [&](float b0, float b1, int yout) {
+    // the key of a row is stored while the NEXT row is scored (store_keys): right behind the row's loads it would queue with them
+    uint32_t key_out = 0u, key2_out = 0u;
+    auto store_keys = [&](int yrow) {
+        const int x = X0 + lane;
+        if (x < a.W - R) {
+            oKeys[((size_t)range * a.H + yrow) * a.out_pitch + x] = __builtin_bit_cast(float, key_out);
+            if (WANT2) oKeys2[((size_t)range * a.H + yrow) * a.out_pitch + x] = __builtin_bit_cast(float, key2_out);
+        }
+    };
+    auto emit = [&](float b0, float b1) {
         // the two half-waves hold different right columns of the same left column: bring them together
         // (lanes 0-31 then own block 0, lanes 32-63 block 1), compare on the 26-bit scores, the larger
         // right column (lower disparity) keeps a tie
@@ -311,14 +334,12 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         const float s1 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, k1) & kmask);
         const bool up = (s1 > s0) || (s1 == s0 && j1 > j0);
         const uint32_t sb = __builtin_bit_cast(uint32_t, up ? s1 : s0);
-        const uint32_t out = (sb & 0xFFFFFF80u) | (uint32_t)(up ? j1 : j0);
-        const int x = X0 + lane;
-        if (x < a.W - R) oKeys[((size_t)range * a.H + yout) * a.out_pitch + x] = __builtin_bit_cast(float, out);
+        key_out = (sb & 0xFFFFFF80u) | (uint32_t)(up ? j1 : j0);
         return up ? j1 : j0;
     };
     // second plane: m1 / m2 = best / second-best key per class of the lane's share of right columns, [block][label];
     // a register's label is its right column's index mod 3 in the lower half-wave, one less than it (mod 3) in the upper
-    auto emit2 = [&](float (&m1)[NB][3], float (&m2)[NB][3], int jstar, int yout) {
+    auto emit2 = [&](float (&m1)[NB][3], float (&m2)[NB][3], int jstar) {
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(m1[0][q]), "+v"(m1[1][q]));   // [0]: the lower half-wave's, [1]: the upper's
@@ -337,9 +358,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
             const float cand = ((unsigned)(jm - jstar + 1) <= 2u) ? nx : hi;
             k2 = cand > k2 ? cand : k2;
         }
-        const uint32_t out = __builtin_bit_cast(uint32_t, k2) & 0xFFFFFF80u;
-        const int x = X0 + lane;
-        if (x < a.W - R) oKeys2[((size_t)range * a.H + yout) * a.out_pitch + x] = __builtin_bit_cast(float, out);
+        key2_out = __builtin_bit_cast(uint32_t, k2) & 0xFFFFFF80u;
     };
 
     // ---- warm-up rows: the window fills, nothing is scored, no correction ----
@@ -375,7 +394,8 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         uint32_t ccur[NB];
 #pragma unroll
         for (int c = 0; c < NB; c++) ccur[c] = CORR ? cpair(fnc[c]) : 0u;
-        fetch(ynew + 1);
+        if constexpr (SPREAD) fetch_part(0, ynew + 1);
+        else fetch(ynew + 1);
         u32x4_t bop[NB][KS];
         load_b(bop, ccur, cprev);
 #pragma unroll
@@ -390,6 +410,13 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         }
 #pragma unroll
         for (int t = 0; t < T; t++) {
+            if (SPREAD && EDGE && t >= 1) {
+                // tiles may be skipped here: the rest of the row's memory operations go between the tiles
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 1) { fetch_part(1, ynew + 1); fetch_part(2, ynew + 1); }
+                if (t == 2) { fetch_part(3, ynew + 1); if (st > 2 * R) store_keys(yout - 1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (EDGE && !((ab >> (t * NB)) & ((1u << NB) - 1u))) continue;
             u32x4_t aop[KS];
             load_a(t, aop, yout);
@@ -405,6 +432,13 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
                 if (!EDGE || ((ab >> (t * NB + c)) & 1u)) slide(t, c, aop, bop);
 #pragma unroll
             for (int c = 0; c < NB; c++) {
+                if (SPREAD && !EDGE && t * NB + c >= 1 && t * NB + c <= 4) {
+                    // one part of the next row's loads, or the previous row's key store, in front of this block's statements
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t * NB + c <= 3) fetch_part(t * NB + c, ynew + 1);
+                    else if (st > 2 * R) store_keys(yout - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (EDGE && !((ab >> (t * NB + c)) & 1u)) continue;
                 float ir[16];
 #pragma unroll
@@ -541,11 +575,13 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
                 const float m01 = m1[c][0] > m1[c][1] ? m1[c][0] : m1[c][1];
                 best[c] = m01 > m1[c][2] ? m01 : m1[c][2];
             }
-            const int jstar = emit(best[0], best[1], yout);
-            emit2(m1, m2, jstar, yout);
+            const int jstar = emit(best[0], best[1]);
+            emit2(m1, m2, jstar);
         } else {
-            emit(best[0], best[1], yout);
+            emit(best[0], best[1]);
         }
+        if constexpr (!SPREAD) store_keys(yout);
     }
+    if (SPREAD && nsteps > 2 * R) store_keys(yb1 - 1);         // the last row's keys
     }
 }
