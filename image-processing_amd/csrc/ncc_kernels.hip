@@ -712,23 +712,29 @@ __global__ __launch_bounds__(NCC_TAIL_NT) void ncc_tail_kernel(
 // Refinement: exact window correlation of the winner and its two neighbours from vertically packed
 // int8 pixels (v_dot4_i32_i8: four rows per instruction), then the same float expression as the
 // argmax kernel, the parabola vertex and the outputs.
-// One workgroup = NCC_REF_BW consecutive pixels of 4 consecutive rows (512 threads, a wavefront is
+// One workgroup = BW consecutive pixels of 4 consecutive rows (4 BW threads, a wavefront is
 // 64 pixels of one row).  Neighbouring pixels need not agree on their disparity (occlusions,
 // mismatches), so per-pixel gathers from global memory would touch whole cache lines for a few
 // bytes each; instead the workgroup stages, once, every quad row its windows touch: the left
 // columns of the run and the right columns of the run for the WHOLE search range, and each pixel
 // then reads its 2R+1 left and 2R+3 right columns from LDS.
-#define NCC_REF_BW 128
+// BW = 64 or 128: runs of 64 pixels stage 1.7 times the columns per pixel but put twice the workgroups on a CU, whose
+// phases (keys, staging, sums, tables) then overlap better -- as long as their LDS images still fit (ncc_refine_bw).
 #ifndef NCC_REFINE_KEY_BATCH
 #define NCC_REFINE_KEY_BATCH 5
 #endif
-template <int R>
+template <int R, int BW>
 struct NccRefineCfg {
     static constexpr int NQ = (2 * R + 7) / 4 + 1;       // quad rows the windows of 4 consecutive rows can touch
-    static constexpr int LC = (NCC_REF_BW + 2 * R + 3) & ~3;     // left columns of the run, row stride a multiple of 4
-    static int right_cols(int nd) { return (NCC_REF_BW + (nd - 1) + 2 * R + 3 + 3) & ~3; }
+    static constexpr int LC = (BW + 2 * R + 3) & ~3;     // left columns of the run, row stride a multiple of 4
+    static int right_cols(int nd) { return (BW + (nd - 1) + 2 * R + 3 + 3) & ~3; }
     static size_t lds_bytes(int nd) { return (size_t)NQ * (LC + right_cols(nd)) * sizeof(uint32_t); }
 };
+// the run width for a search range: 64 while six workgroups of that width fit the CU's 160 KB (+-256 under windows up to
+// 25 x 25, +-384 under 21 x 21), else 128 (measured at 8192 x 4096, 21 x 21: +-64 0.85 / 0.95 ms, +-256 0.87 / 1.02, +-384
+// 1.13 / 1.14, +-512 1.48 / 1.19, +-1000 3.07 / 1.98; 31 x 31 +-256, five workgroups: 1.61 / 1.55)
+template <int R>
+static int ncc_refine_bw(int nd) { return 6 * NccRefineCfg<R, 64>::lds_bytes(nd) <= 160 * 1024 ? 64 : 128; }
 
 // WANT2: the second-peak output (best score further than one disparity from the winner).  Candidates:
 // the winner's chunk contributes its second key plane (lanes further than one lane from its winner),
@@ -740,8 +746,8 @@ struct NccRefineCfg {
 // MF: key planes of the matrix-core kernels (a range of 32*NCC_MF_T right columns per plane, 25-bit score, column
 // index in the range below) instead of the vector kernel's (a chunk of 64 disparities per plane, 26-bit score,
 // 63 - lane below)
-template <int R, bool WANT2, bool MF>
-__global__ __launch_bounds__(512) void ncc_refine_kernel(
+template <int R, bool WANT2, bool MF, int BW>
+__global__ __launch_bounds__(4 * BW) void ncc_refine_kernel(
     NccArgs a, const uint32_t* __restrict__ VL, const uint32_t* __restrict__ VR,
     const float* __restrict__ gNegc, const float* __restrict__ gNegg, const float* __restrict__ gIL,
     const float* __restrict__ gRsr, const float* __restrict__ gRir, const float* __restrict__ gKeys, int nchunk,
@@ -749,18 +755,18 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     const float* __restrict__ gKeys2, float* __restrict__ oPeak2)
 {
     constexpr int range_tiles = MF ? NCC_MF_T : 0;
-    using Cfg = NccRefineCfg<R>;
-    constexpr int NQ = Cfg::NQ, LC = Cfg::LC;
+    using Cfg = NccRefineCfg<R, BW>;
+    constexpr int NQ = Cfg::NQ, LC = Cfg::LC, NT = 4 * BW;
     extern __shared__ __attribute__((aligned(16))) uint32_t ncc_refine_lds[];
-    const int NC = (NCC_REF_BW + (a.dmax - a.dmin) + 2 * R + 3 + 3) & ~3;     // == Cfg::right_cols(nd)
+    const int NC = (BW + (a.dmax - a.dmin) + 2 * R + 3 + 3) & ~3;     // == Cfg::right_cols(nd)
     uint32_t* tL = ncc_refine_lds;               // [NQ][LC]
     uint32_t* tR = ncc_refine_lds + NQ * LC;     // [NQ][NC]
 
     const int tid = threadIdx.x;
     // a wavefront is 64 pixels of ONE row: the row index in a scalar register keeps the window-row masks,
     // the quad tests and the row addresses below on the scalar unit
-    const int lx = tid & (NCC_REF_BW - 1), ly = __builtin_amdgcn_readfirstlane(tid / NCC_REF_BW);
-    const int x0 = R + blockIdx.x * NCC_REF_BW;
+    const int lx = tid & (BW - 1), ly = __builtin_amdgcn_readfirstlane(tid / BW);
+    const int x0 = R + blockIdx.x * BW;
     const int y0 = a.row0 + 4 * blockIdx.y;
     const int x = x0 + lx, y = y0 + ly;
     const bool inside = (x < a.W - R) && (y < a.row1);
@@ -814,25 +820,28 @@ __global__ __launch_bounds__(512) void ncc_refine_kernel(
     // 16 bytes per thread and load; workgroups whose columns all lie inside the pitch (all but those
     // at the left and right edge of the raster) skip the per-element clamps
     const bool interior = (cbase >= 0) && (cbase + NC <= P) && (x0 - R + LC <= P);
-    for (int qi = 0; qi < NQ; qi++) {
-        const int q = min(qb + qi, nq_rows - 1);
-        const uint32_t* lrow = VL + (size_t)q * P + (x0 - R);
-        const uint32_t* rrow = VR + (size_t)q * P;
-        if (interior) {
-            for (int c4 = tid; c4 < (LC + NC) / 4; c4 += 512) {
-                uint4 v;
-                if (c4 < LC / 4) {
-                    __builtin_memcpy(&v, lrow + 4 * c4, 16);                       // 4-byte aligned
-                    *(uint4*)(tL + qi * LC + 4 * c4) = v;
-                } else {
-                    const int c = 4 * c4 - LC;
-                    __builtin_memcpy(&v, rrow + cbase + c, 16);
-                    *(uint4*)(tR + qi * NC + c) = v;
-                }
-            }
-        } else {
-            for (int c = tid; c < LC; c += 512) tL[qi * LC + c] = lrow[min(c, P - 1 - (x0 - R))];
-            for (int c = tid; c < NC; c += 512) tR[qi * NC + c] = rrow[min(max(cbase + c, 0), P - 1)];
+    if (interior) {
+        // a thread owns one 16-byte column group and requests it for ALL quad rows before the first one is written to
+        // LDS: one round trip to memory per workgroup instead of one per quad row
+        for (int c4 = tid; c4 < (LC + NC) / 4; c4 += NT) {
+            const bool left = c4 < LC / 4;
+            const int c = left ? 4 * c4 : 4 * c4 - LC;
+            const uint32_t* src = left ? VL + (x0 - R) + c : VR + cbase + c;      // 4-byte aligned
+            uint32_t* dst = left ? tL + c : tR + c;
+            const int dstep = left ? LC : NC;
+            uint4 v[NQ];
+#pragma unroll
+            for (int qi = 0; qi < NQ; qi++) __builtin_memcpy(&v[qi], src + (size_t)min(qb + qi, nq_rows - 1) * P, 16);
+#pragma unroll
+            for (int qi = 0; qi < NQ; qi++) *(uint4*)(dst + qi * dstep) = v[qi];
+        }
+    } else {
+        for (int qi = 0; qi < NQ; qi++) {
+            const int q = min(qb + qi, nq_rows - 1);
+            const uint32_t* lrow = VL + (size_t)q * P + (x0 - R);
+            const uint32_t* rrow = VR + (size_t)q * P;
+            for (int c = tid; c < LC; c += NT) tL[qi * LC + c] = lrow[min(c, P - 1 - (x0 - R))];
+            for (int c = tid; c < NC; c += NT) tR[qi * NC + c] = rrow[min(max(cbase + c, 0), P - 1)];
         }
     }
     __syncthreads();
@@ -1178,10 +1187,11 @@ static int ncc_launch_fast(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     rc = ncc_join(ctx, w);                         // vertical packs, border, tail
     if (rc) return rc;
     {
-        const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
+        constexpr int BW = 128;                    // the vector kernels' planes: one width
+        const size_t lds = NccRefineCfg<R, BW>::lds_bytes(nd);
         if (lds > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, WANT2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((ncc_refine_kernel<R, WANT2, false>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, WANT2, false, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ncc_refine_kernel<R, WANT2, false, BW>), dim3((a.W - 2 * R + BW - 1) / BW, (a.row1 - a.row0 + 3) / 4), dim3(4 * BW),
                            lds, ctx->stream,
                            a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nplanes, d_disp, d_peak, d_idisp,
                            keys2, d_peak2);
@@ -1238,11 +1248,19 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     rc = ncc_join(ctx, w);                         // vertical packs, border, edge ranges
     if (rc) return rc;
     mis_prof_mark(ctx);
-    {
-        const size_t lds = NccRefineCfg<R>::lds_bytes(nd);
+    if (ncc_refine_bw<R>(nd) == 64) {
+        constexpr int BW = 64;
+        const size_t lds = NccRefineCfg<R, BW>::lds_bytes(nd);
+        hipLaunchKernelGGL((ncc_refine_kernel<R, WANT2, true, BW>), dim3((a.W - 2 * R + BW - 1) / BW, (a.row1 - a.row0 + 3) / 4), dim3(4 * BW),
+                           lds, ctx->stream,
+                           a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nranges, d_disp, d_peak, d_idisp,
+                           keys2, d_peak2);
+    } else {
+        constexpr int BW = 128;
+        const size_t lds = NccRefineCfg<R, BW>::lds_bytes(nd);
         if (lds > 64 * 1024)
-            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, WANT2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((ncc_refine_kernel<R, WANT2, true>), dim3((a.W - 2 * R + NCC_REF_BW - 1) / NCC_REF_BW, (a.row1 - a.row0 + 3) / 4), dim3(512),
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)ncc_refine_kernel<R, WANT2, true, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ncc_refine_kernel<R, WANT2, true, BW>), dim3((a.W - 2 * R + BW - 1) / BW, (a.row1 - a.row0 + 3) / 4), dim3(4 * BW),
                            lds, ctx->stream,
                            a, w->VL, w->VR, w->negc, w->negg, w->iL, w->Rsr, w->Rir, w->keys, nranges, d_disp, d_peak, d_idisp,
                            keys2, d_peak2);
