@@ -366,16 +366,17 @@ __global__ __launch_bounds__(64, 3) void ncc16_argmax_kernel(
 #define NCC16_REF_G 8
 template <int R>
 struct Ncc16RefineCfg {
-    static constexpr int LC = NCC16_REF_BW + 2 * R;
-    static int right_cols(int nd) { return NCC16_REF_BW + (nd - 1) + 2 * R + 3; }
+    static constexpr int LC = (NCC16_REF_BW + 2 * R + 3) & ~3;      // row strides are multiples of 4: 16-byte LDS writes
+    static int right_cols(int nd) { return (NCC16_REF_BW + (nd - 1) + 2 * R + 3 + 3) & ~3; }
     static size_t lds_bytes(int nd) { return (size_t)NCC16_REF_G * (LC + right_cols(nd)) * sizeof(int32_t); }
 };
 
 // WANT2: second-peak output from the two key planes, with the exact score of the disparity two away
 // from the winner where a chunk boundary hid it (see ncc_refine_kernel in ncc_kernels.hip); that
 // candidate's window sum rides along with the other three.
+// (six wavefronts per SIMD = three workgroups per CU: worth the few registers it spills, 2.84 -> 2.65 ms on a 16384 x 1024 band)
 template <int R, bool WANT2>
-__global__ __launch_bounds__(512) void ncc16_refine_kernel(
+__global__ __launch_bounds__(512, 6) void ncc16_refine_kernel(
     NccArgs a, const int32_t* __restrict__ gL, const int32_t* __restrict__ gR,
     const int32_t* __restrict__ gSL, const float* __restrict__ gIL, const int32_t* __restrict__ gSR,
     const float* __restrict__ gIR, const float* __restrict__ gKeys, int nchunk,
@@ -383,8 +384,8 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
     const float* __restrict__ gKeys2, float* __restrict__ oPeak2)
 {
     constexpr int LC = Ncc16RefineCfg<R>::LC, G = NCC16_REF_G;
-    extern __shared__ int32_t ncc16_refine_lds[];
-    const int NC = NCC16_REF_BW + (a.dmax - a.dmin) + 2 * R + 3;
+    extern __shared__ __attribute__((aligned(16))) int32_t ncc16_refine_lds[];
+    const int NC = (NCC16_REF_BW + (a.dmax - a.dmin) + 2 * R + 3 + 3) & ~3;      // == Ncc16RefineCfg<R>::right_cols(nd)
     int32_t* tL = ncc16_refine_lds;               // [G][LC]
     int32_t* tR = ncc16_refine_lds + G * LC;      // [G][NC]
     const int tid = threadIdx.x;
@@ -442,14 +443,34 @@ __global__ __launch_bounds__(512) void ncc16_refine_kernel(
     const int32_t* px = tR + (u2 - R - cbase);                // column u2-R
 
     const int ylo = y0 - R, yhi = min(y0 + 3, a.row1 - 1) + R;   // window rows of the 4 output rows
+    // workgroups whose columns all lie inside the pitch (all but those at the left and right edge of the raster) stage
+    // 16 bytes per thread and load, without per-element clamps
+    const bool interior = (cbase >= 0) && (cbase + NC <= P) && (x0 - R + LC <= P);
     for (int yg = ylo; yg <= yhi; yg += G) {
         __syncthreads();                           // the previous group has been consumed
-        for (int j = 0; j < G; j++) {
-            const int row = min(yg + j, a.H - 1);
-            const int32_t* lrow = gL + (size_t)row * P + (x0 - R);
-            const int32_t* rrow = gR + (size_t)row * P;
-            for (int c = tid; c < LC; c += 512) tL[j * LC + c] = lrow[c];
-            for (int c = tid; c < NC; c += 512) tR[j * NC + c] = rrow[min(max(cbase + c, 0), P - 1)];
+        if (interior) {
+            // a thread owns one 16-byte column group and requests it for ALL rows of the group before the first one is
+            // written to LDS: one round trip to memory per group instead of two per row
+            for (int c4 = tid; c4 < (LC + NC) / 4; c4 += 512) {
+                const bool left = c4 < LC / 4;
+                const int c = left ? 4 * c4 : 4 * c4 - LC;
+                const int32_t* src = left ? gL + (x0 - R) + c : gR + cbase + c;       // 4-byte aligned
+                int32_t* dst = left ? tL + c : tR + c;
+                const int dstep = left ? LC : NC;
+                uint4 v[G];
+#pragma unroll
+                for (int j = 0; j < G; j++) __builtin_memcpy(&v[j], src + (size_t)min(yg + j, a.H - 1) * P, 16);
+#pragma unroll
+                for (int j = 0; j < G; j++) *(uint4*)(dst + j * dstep) = v[j];
+            }
+        } else {
+            for (int j = 0; j < G; j++) {
+                const int row = min(yg + j, a.H - 1);
+                const int32_t* lrow = gL + (size_t)row * P + (x0 - R);
+                const int32_t* rrow = gR + (size_t)row * P;
+                for (int c = tid; c < LC; c += 512) tL[j * LC + c] = lrow[min(c, P - 1 - (x0 - R))];
+                for (int c = tid; c < NC; c += 512) tR[j * NC + c] = rrow[min(max(cbase + c, 0), P - 1)];
+            }
         }
         __syncthreads();
         if (!valid) continue;
