@@ -201,9 +201,20 @@ def issue_floor(W, H, window, nd, kernel_s):
     scored_ns = 96 * per_reg + 6 * ks * 8 / 2.1
     warm_ns = 6 * ks * 32 / 2.1
     floor_s = blocks * ranges * (rows * scored_ns + bands * 2 * r * warm_ns) * 1e-9 / 1024
+    # The same mix priced at the kernel's own occupancy (tools/ubench/mfma_valu_overlap, two wavefronts per SIMD):
+    # v_mul / v_fmac / v_fma take 2 clocks of the vector pipe and do not overlap with products in flight, v_and_or /
+    # v_max3 and the 85 other vector instructions of a row (operand selects, statistics, key merge; counted in the
+    # ISA) take 4; a product 32.  Clock: 2.25 GHz, what SQ_BUSY_CYCLES over the kernel's duration gives (profiles/).
+    fast = 2 * 96 + (96 if window > 21 else 0)
+    scored_clk = fast * 2 + (96 + 48 + 85) * 4 + 6 * ks * 32
+    warm_clk = 40 * 4 + 6 * ks * 32
+    pipes_s = blocks * ranges * (rows * scored_clk + bands * 2 * r * warm_clk) / 2.25e9 / 1024
     return {"ms": round(floor_s * 1e3, 3), "frac": round(floor_s / kernel_s, 3) if kernel_s > 0 else None,
             "note": "vector-issue floor of the matrix-core kernel's instruction mix (prices at 8 wavefronts per SIMD; "
-                    "the kernel's 96 accumulators allow 2) / measured kernel time"}
+                    "the kernel's 96 accumulators allow 2) / measured kernel time",
+            "two_wavefronts": {"ms": round(pipes_s * 1e3, 3), "frac": round(pipes_s / kernel_s, 3) if kernel_s > 0 else None,
+                               "note": "vector + matrix pipe time of the same mix at 2 wavefronts per SIMD, where multiplications "
+                                       "and products do not overlap (microbenchmark prices, 2.25 GHz): a model, not a bound"}}
 
 
 def mfma_rate(W, H, window, nd, kernel_s):
