@@ -60,11 +60,14 @@ __global__ __launch_bounds__(64) void k(long long* out, float seed)
 #define XORV(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[i]) : "v"(b));
 #define LSHL(i) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(r[i]));
 #define SUBS(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(r[i]) : "s"(sm));
+#define MULQ(i) asm volatile("v_mul_f32_dpp %0, %1, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(r[i]) : "v"(b));
+#define MACQ(i) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(r[i]) : "v"(b), "v"(c));
         if (OP == 0) { REP16(FMA) } if (OP == 1) { REP16(ADD) } if (OP == 2) { REP16(PKF) } if (OP == 3) { REP16(PKA) }
         if (OP == 4) { REP16(DOT) } if (OP == 5) { REP16(DPP) } if (OP == 6) { REP16(AOR) } if (OP == 7) { REP16(SWP) }
         if (OP == 8) { REP16(CND) } if (OP == 9) { REP16(F64) } if (OP == 10) { REP16(MUL) } if (OP == 11) { REP16(CVT) }
         if (OP == 16) { REP16(SUBV) } if (OP == 17) { REP16(MULV) } if (OP == 18) { REP16(ADDS) } if (OP == 19) { REP16(FMAN) } if (OP == 20) { REP16(ADDN) } if (OP == 21) { REP16(ADDU) } if (OP == 22) { REP16(MOVV) } if (OP == 23) { REP16(FMAS) } if (OP == 24) { REP16(FMAC) }
         if (OP == 25) { REP16(AORV) } if (OP == 26) { REP16(ANDV) } if (OP == 27) { REP16(ORV) } if (OP == 28) { REP16(MAXI) } if (OP == 29) { REP16(MAXU) } if (OP == 30) { REP16(MINF) } if (OP == 31) { REP16(MAX3) } if (OP == 32) { REP16(PKFS) } if (OP == 33) { REP16(PKM) } if (OP == 34) { REP16(BFI) } if (OP == 35) { REP16(LSO) } if (OP == 36) { REP16(CVTI) } if (OP == 37) { REP16(DOT3) } if (OP == 38) { REP16(XORV) } if (OP == 39) { REP16(LSHL) }
+        if (OP == 40) { REP16(MULQ) } if (OP == 41) { REP16(MACQ) } if (OP == 17) { }
         if (OP == 12) { REP16(D4) } if (OP == 13) { REP16(MAX) } if (OP == 14) { REP16(SW16) } if (OP == 15) { REP16(SUBS) }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -100,6 +103,7 @@ int main(int argc, char** argv)
     printf("waves per SIMD: %d (s_memtime ticks at a fixed 100 MHz on this part if the cyc columns look 24x small)\n", wps);
     for (int rep = 0; rep < 2; rep++) {
         run<0>("v_fma_f32", wps, d); run<13>("v_max_f32", wps, d);
+        run<24>("v_fmac_f32", wps, d); run<40>("v_mul_f32_dpp quad_perm", wps, d); run<41>("v_fmac_f32_dpp quad_perm", wps, d);
         run<25>("v_and_or_b32 vgpr", wps, d); run<26>("v_and_b32", wps, d); run<27>("v_or_b32", wps, d); run<38>("v_xor_b32", wps, d); run<39>("v_lshlrev_b32", wps, d);
         run<28>("v_max_i32", wps, d); run<29>("v_max_u32", wps, d); run<30>("v_min_f32", wps, d); run<31>("v_max3_f32", wps, d);
         run<2>("v_pk_fma_f32 vgpr", wps, d); run<32>("v_pk_fma_f32 sgpr", wps, d); run<33>("v_pk_mul_f32", wps, d);
