@@ -372,7 +372,7 @@ struct Ncc16RefineCfg {
 };
 
 // WANT2: second-peak output from the two key planes, with the exact score of the disparity two away
-// from the winner where a chunk boundary hid it (see ncc_refine_kernel in ncc_kernels.hip); that
+// from the winner where a chunk boundary hid it (see ncc_refine_kernel in ncc_refine_kernels.hip); that
 // candidate's window sum rides along with the other three.
 // (six wavefronts per SIMD = three workgroups per CU: worth the few registers it spills, 2.84 -> 2.65 ms on a 16384 x 1024 band)
 template <int R, bool WANT2>
