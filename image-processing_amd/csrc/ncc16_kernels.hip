@@ -464,12 +464,19 @@ __global__ __launch_bounds__(512, 6) void ncc16_refine_kernel(
                 for (int j = 0; j < G; j++) *(uint4*)(dst + j * dstep) = v[j];
             }
         } else {
-            for (int j = 0; j < G; j++) {
-                const int row = min(yg + j, a.H - 1);
-                const int32_t* lrow = gL + (size_t)row * P + (x0 - R);
-                const int32_t* rrow = gR + (size_t)row * P;
-                for (int c = tid; c < LC; c += 512) tL[j * LC + c] = lrow[min(c, P - 1 - (x0 - R))];
-                for (int c = tid; c < NC; c += 512) tR[j * NC + c] = rrow[min(max(cbase + c, 0), P - 1)];
+            // at the raster's left and right edge: one column per thread, clamped into the pitch, again all rows of the
+            // group requested before the first LDS write
+            for (int c = tid; c < LC + NC; c += 512) {
+                const bool left = c < LC;
+                const int cc = left ? c : c - LC;
+                const int32_t* src = left ? gL + min(x0 - R + cc, P - 1) : gR + min(max(cbase + cc, 0), P - 1);
+                int32_t* dst = left ? tL + cc : tR + cc;
+                const int dstep = left ? LC : NC;
+                int32_t v[G];
+#pragma unroll
+                for (int j = 0; j < G; j++) v[j] = src[(size_t)min(yg + j, a.H - 1) * P];
+#pragma unroll
+                for (int j = 0; j < G; j++) dst[j * dstep] = v[j];
             }
         }
         __syncthreads();

@@ -128,12 +128,19 @@ __global__ __launch_bounds__(4 * BW) void ncc_refine_kernel(
             for (int qi = 0; qi < NQ; qi++) *(uint4*)(dst + qi * dstep) = v[qi];
         }
     } else {
-        for (int qi = 0; qi < NQ; qi++) {
-            const int q = min(qb + qi, nq_rows - 1);
-            const uint32_t* lrow = VL + (size_t)q * P + (x0 - R);
-            const uint32_t* rrow = VR + (size_t)q * P;
-            for (int c = tid; c < LC; c += NT) tL[qi * LC + c] = lrow[min(c, P - 1 - (x0 - R))];
-            for (int c = tid; c < NC; c += NT) tR[qi * NC + c] = rrow[min(max(cbase + c, 0), P - 1)];
+        // at the raster's left and right edge: one column per thread, clamped into the pitch, again all quad rows
+        // requested before the first LDS write
+        for (int c = tid; c < LC + NC; c += NT) {
+            const bool left = c < LC;
+            const int cc = left ? c : c - LC;
+            const uint32_t* src = left ? VL + min(x0 - R + cc, P - 1) : VR + min(max(cbase + cc, 0), P - 1);
+            uint32_t* dst = left ? tL + cc : tR + cc;
+            const int dstep = left ? LC : NC;
+            uint32_t v[NQ];
+#pragma unroll
+            for (int qi = 0; qi < NQ; qi++) v[qi] = src[(size_t)min(qb + qi, nq_rows - 1) * P];
+#pragma unroll
+            for (int qi = 0; qi < NQ; qi++) dst[qi * dstep] = v[qi];
         }
     }
     __syncthreads();
