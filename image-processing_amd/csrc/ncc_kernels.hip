@@ -228,14 +228,16 @@ __global__ __launch_bounds__(256) void ncc_vpack_kernel(const T* __restrict__ im
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int q = q0 + blockIdx.y;
     if (x >= pitch) return;
-    uint32_t v = 0;
-    if (x < W) {
+    // the four rows are requested together (clamped coordinates) and tested afterwards: a load inside a condition is
+    // waited for on the spot, four memory round trips in a row
+    const int xc = min(x, W - 1);
+    int p[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int y = 4 * q + k;
-            if (y < H) v |= (uint32_t)(((int)img[(size_t)y * stride_px + x] - 128) & 0xFF) << (8 * k);
-        }
-    }
+    for (int k = 0; k < 4; k++) p[k] = (int)img[(size_t)min(4 * q + k, H - 1) * stride_px + xc];
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (x < W && 4 * q + k < H) v |= (uint32_t)((p[k] - 128) & 0xFF) << (8 * k);
     out[(size_t)q * pitch + x] = v;
 }
 
