@@ -72,7 +72,11 @@ struct NccMfCfg {
 // its winner (the second peak's candidate; the refinement merges the ranges).  Right columns fall into three
 // classes by index mod 3; the winner and its two neighbours sit in three different classes, so the best two keys
 // of every class are enough: a class whose best is one of the three contributes its second best.
-template <int R, bool EDGE, bool WANT2>
+// ANYM / PARTM (bit t*NB + c): a launch for ONE range whose tiles are known when the kernel is compiled -- ANYM the
+// tiles that hold candidates at all, PARTM those that have to be masked per element (EDGE = false, range = seg0).  The
+// first range of every search and the last ranges of the usual +-2^k searches get such kernels (NCC_MF_PATTERNS): the
+// run-time tests of the EDGE kernel cost it a quarter of its speed, and those ranges are a third of a +-256 search.
+template <int R, bool EDGE, bool WANT2, uint32_t ANYM = 0u, uint32_t PARTM = 0u>
 __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     NccArgs a, int nblocks, int nranges, int seg0, int seg1,
     const uint32_t* __restrict__ gLpack, const float* __restrict__ gNegc, const float* __restrict__ gNegg,
@@ -88,6 +92,12 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     static_assert(NB == 2, "the half-wave merge pairs two column blocks");
     static_assert(16 * T <= 64, "register tags are inline constants");
     static_assert(T == 3, "the scored rows place their memory operations by tile and column block");
+    constexpr bool SPEC = ANYM != 0u;             // tiles fixed at compile time
+    static_assert(!SPEC || !EDGE, "a launch with compile-time tiles maps its range like the interior kernel");
+    static_assert((PARTM & ~ANYM) == 0u && ANYM < (1u << (T * NB)), "tile masks");
+    constexpr uint32_t ANYC = SPEC ? ANYM : (1u << (T * NB)) - 1u;
+    // the k-th present tile of a row, counted over (t, c) in order: where the row's memory operations go
+    constexpr int NPRESENT = __builtin_popcount(ANYC);
     // the scored rows spread their loads and the key store over the row (see fetch_part); with four products per tile the
     // kernels have no registers to spare for the longer live ranges and keep the burst at the top of the row
     constexpr bool SPREAD = KS <= 3;
@@ -138,8 +148,8 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
             any_bits |= (uint32_t)any << (t * NB + c);
             part_bits |= (uint32_t)(any && !full) << (t * NB + c);
         }
-    any_bits = __builtin_amdgcn_readfirstlane(any_bits);
-    part_bits = __builtin_amdgcn_readfirstlane(part_bits);
+    any_bits = SPEC ? ANYM : __builtin_amdgcn_readfirstlane(any_bits);
+    part_bits = SPEC ? PARTM : __builtin_amdgcn_readfirstlane(part_bits);
 
     // ---- staging: global -> registers (a row ahead) -> LDS ----
     // position s of the 16-byte grid: copy s / Q, slot s % Q; copy c, slot q holds pixels 4q+c .. 4q+c+3
@@ -361,6 +371,27 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         key2_out = __builtin_bit_cast(uint32_t, k2) & 0xFFFFFF80u;
     };
 
+    // masked tiles of a launch with compile-time tiles: 1 where the element's disparity lies in the range, NaN elsewhere
+    // (the tests do not depend on the row; up to two such tiles keep their factors in registers)
+    constexpr int NPART = __builtin_popcount(SPEC ? PARTM : 0u);
+    constexpr int NPART_HELD = (NPART >= 1 && NPART <= 2) ? NPART : 0;
+    float nanm[NPART_HELD > 0 ? NPART_HELD : 1][16];
+    if constexpr (NPART_HELD > 0) {
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                if (!((PARTM >> (t * NB + c)) & 1u)) continue;
+                const int kp = __builtin_popcount(PARTM & ((1u << (t * NB + c)) - 1u));
+                const int vb = 32 * (T * range + t - c) + 4 * h - n;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const bool in = (unsigned)(vb + 8 * (i >> 2) + (i & 3)) <= (unsigned)(nd - 1);
+                    nanm[kp < NPART_HELD ? kp : 0][i] = in ? 1.0f : __builtin_bit_cast(float, qnan);
+                }
+            }
+    }
+
     // ---- warm-up rows: the window fills, nothing is scored, no correction ----
     const uint32_t zero2[NB] = { 0u, 0u };
     fetch(yb0 - R);
@@ -371,12 +402,12 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         load_b(bop, zero2, zero2);
 #pragma unroll
         for (int t = 0; t < T; t++) {
-            if (EDGE && !((any_bits >> (t * NB)) & ((1u << NB) - 1u))) continue;
+            if (SPEC ? !((ANYM >> (t * NB)) & ((1u << NB) - 1u)) : (EDGE && !((any_bits >> (t * NB)) & ((1u << NB) - 1u)))) continue;
             u32x4_t aop[KS];
             load_a(t, aop, 0);
 #pragma unroll
             for (int c = 0; c < NB; c++)
-                if (!EDGE || ((any_bits >> (t * NB + c)) & 1u)) slide(t, c, aop, bop);
+                if (SPEC ? ((ANYM >> (t * NB + c)) & 1u) != 0u : (!EDGE || ((any_bits >> (t * NB + c)) & 1u))) slide(t, c, aop, bop);
         }
         // the row published by the last warm-up step is the first scored one: its statistics go to its slot
         publish(st + 1 < WN, st + 1 == 2 * R ? yb0 : yb0 - 1);
@@ -394,7 +425,7 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         uint32_t ccur[NB];
 #pragma unroll
         for (int c = 0; c < NB; c++) ccur[c] = CORR ? cpair(fnc[c]) : 0u;
-        if constexpr (SPREAD) fetch_part(0, ynew + 1);
+        if constexpr (SPREAD && NPRESENT >= 5) fetch_part(0, ynew + 1);
         else fetch(ynew + 1);
         u32x4_t bop[NB][KS];
         load_b(bop, ccur, cprev);
@@ -410,14 +441,14 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         }
 #pragma unroll
         for (int t = 0; t < T; t++) {
-            if (SPREAD && EDGE && t >= 1) {
+            if (SPREAD && EDGE && t >= 1) {                // (EDGE: all six tiles may be present)
                 // tiles may be skipped here: the rest of the row's memory operations go between the tiles
                 __builtin_amdgcn_sched_barrier(0);
                 if (t == 1) { fetch_part(1, ynew + 1); fetch_part(2, ynew + 1); }
                 if (t == 2) { fetch_part(3, ynew + 1); if (st > 2 * R) store_keys(yout - 1); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (EDGE && !((ab >> (t * NB)) & ((1u << NB) - 1u))) continue;
+            if (SPEC ? !((ANYM >> (t * NB)) & ((1u << NB) - 1u)) : (EDGE && !((ab >> (t * NB)) & ((1u << NB) - 1u)))) continue;
             u32x4_t aop[KS];
             load_a(t, aop, yout);
             f32x4_t irv[4], qv[4], srv[4];
@@ -429,13 +460,16 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
             }
 #pragma unroll
             for (int c = 0; c < NB; c++)
-                if (!EDGE || ((ab >> (t * NB + c)) & 1u)) slide(t, c, aop, bop);
+                if (SPEC ? ((ANYM >> (t * NB + c)) & 1u) != 0u : (!EDGE || ((ab >> (t * NB + c)) & 1u))) slide(t, c, aop, bop);
 #pragma unroll
             for (int c = 0; c < NB; c++) {
-                if (SPREAD && !EDGE && t * NB + c >= 1 && t * NB + c <= 4) {
+                if (SPEC && !((ANYM >> (t * NB + c)) & 1u)) continue;
+                // the k-th present block of the row (k = t * NB + c where all six are)
+                const int kblk = __builtin_popcount(ANYC & ((1u << (t * NB + c)) - 1u));
+                if (SPREAD && !EDGE && NPRESENT >= 5 && kblk >= 1 && kblk <= 4) {
                     // one part of the next row's loads, or the previous row's key store, in front of this block's statements
                     __builtin_amdgcn_sched_barrier(0);
-                    if (t * NB + c <= 3) fetch_part(t * NB + c, ynew + 1);
+                    if (kblk <= 3) fetch_part(kblk, ynew + 1);
                     else if (st > 2 * R) store_keys(yout - 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -443,7 +477,16 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
                 float ir[16];
 #pragma unroll
                 for (int i = 0; i < 16; i++) ir[i] = irv[i >> 2][i & 3];
-                if (EDGE && ((pb >> (t * NB + c)) & 1u)) {
+                if constexpr (SPEC && NPART_HELD > 0) {
+                    // masked tiles of a launch with compile-time tiles: the per-element factors (1 or NaN) were laid down
+                    // in registers before the rows, one multiplication per element
+                    if ((PARTM >> (t * NB + c)) & 1u) {
+                        const int kp = __builtin_popcount(PARTM & ((1u << (t * NB + c)) - 1u));
+#pragma unroll
+                        for (int i = 0; i < 16; i++) ir[i] *= nanm[kp < NPART_HELD ? kp : 0][i];
+                    }
+                } else
+                if (SPEC ? ((PARTM >> (t * NB + c)) & 1u) != 0u : (EDGE && ((pb >> (t * NB + c)) & 1u))) {
                     // a tile on the edge of the disparity range: 0 <= 32g + (m - n) <= nd - 1 decides per element;
                     // elements outside get a NaN factor and drop out of the maximum (the empty statement keeps
                     // the tests inside this rarely taken branch)
@@ -580,8 +623,8 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
         } else {
             emit(best[0], best[1]);
         }
-        if constexpr (!SPREAD) store_keys(yout);
+        if constexpr (!(SPREAD && (EDGE || NPRESENT >= 5))) store_keys(yout);
     }
-    if (SPREAD && nsteps > 2 * R) store_keys(yb1 - 1);         // the last row's keys
+    if (SPREAD && (EDGE || NPRESENT >= 5) && nsteps > 2 * R) store_keys(yb1 - 1);         // the last row's keys
     }
 }

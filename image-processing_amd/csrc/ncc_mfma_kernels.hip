@@ -2,6 +2,47 @@
 #include "ncc_ws.h"
 #include "ncc_mfma.h"
 
+#include <stdlib.h>
+
+// ---- edge ranges with compile-time tiles ----
+// tiles (t, c) of range r: diagonal g = T r + t - c of the 32 x 32 tile grid; present while 0 <= g <= G, masked per element
+// unless every element lies inside the disparity range (the kernel's own rule)
+static void ncc_mf_tile_masks(int r, int nd, uint32_t& any_bits, uint32_t& part_bits)
+{
+    const int G = (nd + 30) >> 5;
+    any_bits = part_bits = 0u;
+    for (int t = 0; t < NCC_MF_T; t++)
+        for (int c = 0; c < NCC_MF_NB; c++) {
+            const int g = NCC_MF_T * r + t - c;
+            const bool any = g >= 0 && g <= G, full = g >= 1 && 32 * g + 31 <= nd - 1;
+            any_bits |= (uint32_t)any << (t * NCC_MF_NB + c);
+            part_bits |= (uint32_t)(any && !full) << (t * NCC_MF_NB + c);
+        }
+}
+// The patterns that have kernels: the first range of any search of 96 disparities or more, and the last ranges of searches
+// of 32 G + 1 disparities (+-64, +-128, +-256, +-512, ...): G = 1 (mod 3) ends in one range (tiles on diagonals G and G + 1),
+// G = 2 (mod 3) in two (the last one holds a single masked tile).
+#define NCC_MF_PATTERNS(X) X(0x3Du, 0x09u) X(0x2Fu, 0x24u) X(0x3Fu, 0x10u) X(0x02u, 0x02u)
+static bool ncc_mf_has_pattern(uint32_t any_bits, uint32_t part_bits)
+{
+#define NCC_MF_HAS(A, B) if (any_bits == A && part_bits == B) return true;
+    NCC_MF_PATTERNS(NCC_MF_HAS)
+#undef NCC_MF_HAS
+    return false;
+}
+template <int R>
+static void ncc_mf_launch_pattern(uint32_t any_bits, uint32_t part_bits, dim3 grid, hipStream_t s, NccArgs a, int nblocks, int range,
+                                  const uint32_t* Lpack, const float* negc, const float* negg, const uint32_t* Rpack,
+                                  const float* Rsr, const float* Rir, float* keys)
+{
+#define NCC_MF_GO(A, B) if (any_bits == A && part_bits == B) { \
+        hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, false, false, A, B>), grid, dim3(64), 0, s, \
+                           a, nblocks, 1, range, 0, Lpack, negc, negg, Rpack, Rsr, Rir, keys, (float*)nullptr); return; }
+    NCC_MF_PATTERNS(NCC_MF_GO)
+#undef NCC_MF_GO
+}
+static const int spec_env = [] { const char* e = getenv("MISTEREO_NCC_EDGE_SPEC"); return e ? atoi(e) : 1; }();     // 0: the run-time edge kernel (A/B switch)
+
 // Matrix-core path: one key plane per range of 32*NCC_MF_T right columns, no tail kernel (the tiles on the
 // edge of the disparity range are masked per element).
 template <int R, bool WANT2>
@@ -40,6 +81,22 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
             MIS_HIP(ctx, hipStreamWaitEvent(w->side, w->ev_main, 0));
             se = w->side;
         }
+        // edge ranges whose tiles match a compile-time pattern run as one launch each, without the run-time tile tests
+        bool spec = !WANT2 && n_edge > 0 && spec_env != 0;
+        uint32_t any_r[8], part_r[8]; int edge_r[8]; int ne = 0;
+        for (int r = 0; spec && r < nranges; r++) {
+            if (n_in > 0 && r >= p_lo && r <= p_hi) continue;
+            if (ne == 8) { spec = false; break; }
+            ncc_mf_tile_masks(r, nd, any_r[ne], part_r[ne]);
+            if (any_r[ne] == 0u) continue;         // no candidates at all in this range: nothing to launch
+            spec = ncc_mf_has_pattern(any_r[ne], part_r[ne]);
+            edge_r[ne++] = r;
+        }
+        if (spec) {
+            for (int i = 0; i < ne; i++)
+                ncc_mf_launch_pattern<R>(any_r[i], part_r[i], dim3((unsigned)(nblocks * a.nbands)), se,
+                                         a, nblocks, edge_r[i], w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+        } else
         if (n_edge > 0)
             hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, true, WANT2>), dim3((unsigned)(nblocks * a.nbands * n_edge)), dim3(64), 0, se,
                                a, nblocks, n_edge, n_in > 0 ? p_lo : nranges, p_hi + 1, w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys, keys2);
