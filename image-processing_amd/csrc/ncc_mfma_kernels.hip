@@ -30,14 +30,14 @@ static bool ncc_mf_has_pattern(uint32_t any_bits, uint32_t part_bits)
 #undef NCC_MF_HAS
     return false;
 }
-template <int R>
+template <int R, bool WANT2>
 static void ncc_mf_launch_pattern(uint32_t any_bits, uint32_t part_bits, dim3 grid, hipStream_t s, NccArgs a, int nblocks, int range,
                                   const uint32_t* Lpack, const float* negc, const float* negg, const uint32_t* Rpack,
-                                  const float* Rsr, const float* Rir, float* keys)
+                                  const float* Rsr, const float* Rir, float* keys, float* keys2)
 {
 #define NCC_MF_GO(A, B) if (any_bits == A && part_bits == B) { \
-        hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, false, false, A, B>), grid, dim3(64), 0, s, \
-                           a, nblocks, 1, range, 0, Lpack, negc, negg, Rpack, Rsr, Rir, keys, (float*)nullptr); return; }
+        hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, false, WANT2, A, B>), grid, dim3(64), 0, s, \
+                           a, nblocks, 1, range, 0, Lpack, negc, negg, Rpack, Rsr, Rir, keys, keys2); return; }
     NCC_MF_PATTERNS(NCC_MF_GO)
 #undef NCC_MF_GO
 }
@@ -82,7 +82,7 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
             se = w->side;
         }
         // edge ranges whose tiles match a compile-time pattern run as one launch each, without the run-time tile tests
-        bool spec = !WANT2 && n_edge > 0 && spec_env != 0;
+        bool spec = n_edge > 0 && spec_env != 0;
         uint32_t any_r[8], part_r[8]; int edge_r[8]; int ne = 0;
         for (int r = 0; spec && r < nranges; r++) {
             if (n_in > 0 && r >= p_lo && r <= p_hi) continue;
@@ -94,8 +94,8 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
         }
         if (spec) {
             for (int i = 0; i < ne; i++)
-                ncc_mf_launch_pattern<R>(any_r[i], part_r[i], dim3((unsigned)(nblocks * a.nbands)), se,
-                                         a, nblocks, edge_r[i], w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys);
+                ncc_mf_launch_pattern<R, WANT2>(any_r[i], part_r[i], dim3((unsigned)(nblocks * a.nbands)), se,
+                                                a, nblocks, edge_r[i], w->Lpack, w->negc, w->negg, w->Rpack, w->Rsr, w->Rir, w->keys, keys2);
         } else
         if (n_edge > 0)
             hipLaunchKernelGGL((ncc_mfma_argmax_kernel<R, true, WANT2>), dim3((unsigned)(nblocks * a.nbands * n_edge)), dim3(64), 0, se,
