@@ -224,6 +224,19 @@ def test_every_window_of_the_matrix_core_path(ctx, window):
         assert st["valid"] > 0
 
 
+@pytest.mark.parametrize("window", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31])
+def test_edge_ranges_with_compile_time_tiles(ctx, window):
+    """Searches of 32 G + 1 disparities (+-64: the last range holds diagonals G and G + 1; +-128: two last ranges, the very
+    last one a single masked tile) run their first and last ranges of right columns as launches whose tiles are fixed at
+    compile time; every window, with and without the second peak, against the oracle."""
+    for k, (dmin, dmax) in enumerate([(-64, 64), (-128, 128), (-100, 28), (3, 259)]):
+        h, w = 2 * window + 7 + k, 300 + 40 * k + (dmax - dmin)
+        left = synth.texture(h, w, 900 + 31 * window + k)
+        right = synth.shift_right_image(left, (dmin + dmax) // 2 + 5 - 3 * k, fill_seed=k + 20)
+        st = _run(ctx, left, right, window, dmin, dmax, peak2=(k % 2 == 1))
+        assert st["valid"] > 0
+
+
 def test_widest_search_range_on_the_matrix_core_path(ctx):
     """2048 disparities (the API's limit) are 22 key planes of 96 right columns; the frame is narrower than the range,
     so most candidates of most pixels fall off the raster."""
