@@ -372,9 +372,9 @@ __global__ __launch_bounds__(64, 2) void ncc_mfma_argmax_kernel(
     };
 
     // masked tiles of a launch with compile-time tiles: 1 where the element's disparity lies in the range, NaN elsewhere
-    // (the tests do not depend on the row; up to two such tiles keep their factors in registers)
+    // (the tests do not depend on the row; the factors stay in registers where accumulators and factors together fit)
     constexpr int NPART = __builtin_popcount(SPEC ? PARTM : 0u);
-    constexpr int NPART_HELD = (NPART >= 1 && NPART <= 2) ? NPART : 0;
+    constexpr int NPART_HELD = (NPART >= 1 && NPRESENT + NPART <= 7) ? NPART : 0;      // 16 registers per tile, present or masked: at most 112
     float nanm[NPART_HELD > 0 ? NPART_HELD : 1][16];
     if constexpr (NPART_HELD > 0) {
 #pragma unroll

@@ -19,10 +19,12 @@ static void ncc_mf_tile_masks(int r, int nd, uint32_t& any_bits, uint32_t& part_
             part_bits |= (uint32_t)(any && !full) << (t * NCC_MF_NB + c);
         }
 }
-// The patterns that have kernels: the first range of any search of 96 disparities or more, and the last ranges of searches
-// of 32 G + 1 disparities (+-64, +-128, +-256, +-512, ...): G = 1 (mod 3) ends in one range (tiles on diagonals G and G + 1),
-// G = 2 (mod 3) in two (the last one holds a single masked tile).
-#define NCC_MF_PATTERNS(X) X(0x3Du, 0x09u) X(0x2Fu, 0x24u) X(0x3Fu, 0x10u) X(0x02u, 0x02u)
+// The patterns that have kernels: the first range of any search of 96 disparities or more; the last ranges of searches
+// of 32 G + 1 disparities (+-64, +-128, +-256, +-512, ...: only diagonal G is masked): G = 1 (mod 3) ends in one range,
+// G = 2 (mod 3) in two (the last one holds a single masked tile); and the last ranges of the general case, where the two
+// last diagonals are masked, for G = 0, 1, 2 (mod 3).  1911 of the 2048 search sizes the API takes (all from 96 on but
+// a few multiples of 32) find all their edge ranges here; the others run the kernel that tests its tiles at run time.
+#define NCC_MF_PATTERNS(X) X(0x3Du, 0x09u) X(0x2Fu, 0x24u) X(0x3Fu, 0x10u) X(0x02u, 0x02u) X(0x0Bu, 0x0Bu) X(0x2Fu, 0x2Du) X(0x3Fu, 0x34u)
 static bool ncc_mf_has_pattern(uint32_t any_bits, uint32_t part_bits)
 {
 #define NCC_MF_HAS(A, B) if (any_bits == A && part_bits == B) return true;
@@ -113,10 +115,22 @@ static int ncc_launch_mfma(mis_ctx* ctx, NccArgs a, float* d_disp, float* d_peak
     return MIS_OK;
 }
 
+// This file is compiled twice (the second time through ncc_mfma2_kernels.hip, which sets NCC_MF_WANT2): the kernels with
+// and without the second-peak plane are two translation units that compile side by side.
+#ifndef NCC_MF_WANT2
+#define NCC_MF_WANT2 0
+#endif
+#if NCC_MF_WANT2
+int ncc_mfma_launch_peak2(mis_ctx* ctx, int r, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
+{
+#define NCC_MCASE(RR) case RR: return ncc_launch_mfma<RR, true>(ctx, a, d_disp, d_peak, d_idisp, d_peak2);
+#else
+int ncc_mfma_launch_peak2(mis_ctx* ctx, int r, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2);
 int ncc_mfma_launch(mis_ctx* ctx, int r, NccArgs a, float* d_disp, float* d_peak, int16_t* d_idisp, float* d_peak2)
 {
-#define NCC_MCASE(RR) case RR: return d_peak2 ? ncc_launch_mfma<RR, true>(ctx, a, d_disp, d_peak, d_idisp, d_peak2) \
-                                              : ncc_launch_mfma<RR, false>(ctx, a, d_disp, d_peak, d_idisp, nullptr);
+    if (d_peak2) return ncc_mfma_launch_peak2(ctx, r, a, d_disp, d_peak, d_idisp, d_peak2);
+#define NCC_MCASE(RR) case RR: return ncc_launch_mfma<RR, false>(ctx, a, d_disp, d_peak, d_idisp, nullptr);
+#endif
     switch (r) {
         NCC_MCASE(1) NCC_MCASE(2) NCC_MCASE(3) NCC_MCASE(4) NCC_MCASE(5) NCC_MCASE(6) NCC_MCASE(7) NCC_MCASE(8)
         NCC_MCASE(9) NCC_MCASE(10) NCC_MCASE(11) NCC_MCASE(12) NCC_MCASE(13) NCC_MCASE(14) NCC_MCASE(15)

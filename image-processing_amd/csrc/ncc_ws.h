@@ -1,8 +1,9 @@
 // Workspace of the 8-bit dense NCC and the entry points its translation units share, gfx950.
 //   csrc/ncc_kernels.hip         tables, vertical packs, vector argmax kernels, border, the call's orchestration
 //   csrc/ncc_mfma_kernels.hip    argmax on the matrix cores (ncc_mfma.h) and its launches
+//   csrc/ncc_mfma2_kernels.hip   the same file once more: the kernels that also write the second-peak plane
 //   csrc/ncc_refine_kernels.hip  key merge, exact scores, subpixel: the refinement both argmax paths feed
-// (three units so that their many template instantiations compile side by side)
+// (several units so that their many template instantiations compile side by side)
 #pragma once
 
 #include "ncc_shared.h"
