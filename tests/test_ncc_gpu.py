@@ -237,6 +237,18 @@ def test_edge_ranges_with_compile_time_tiles(ctx, window):
         assert st["valid"] > 0
 
 
+@pytest.mark.parametrize("window", [3, 7, 9, 13, 15, 19, 21, 23, 27, 31])
+def test_edge_ranges_of_general_search_sizes(ctx, window):
+    """Searches whose size is not 32 G + 1 mask two diagonals in their last range; the three residues of G mod 3 (201, 233
+    and 265 disparities) and a short search of one range take one compile-time tile pattern each."""
+    for k, (dmin, dmax) in enumerate([(-100, 100), (-116, 116), (-132, 132), (-20, 50)]):
+        h, w = 2 * window + 5 + k, 280 + 24 * k + (dmax - dmin)
+        left = synth.texture(h, w, 1700 + 17 * window + k)
+        right = synth.shift_right_image(left, (dmin + dmax) // 2 - 7 + 4 * k, fill_seed=k + 40)
+        st = _run(ctx, left, right, window, dmin, dmax, peak2=(k % 2 == 0))
+        assert st["valid"] > 0
+
+
 def test_widest_search_range_on_the_matrix_core_path(ctx):
     """2048 disparities (the API's limit) are 22 key planes of 96 right columns; the frame is narrower than the range,
     so most candidates of most pixels fall off the raster."""
