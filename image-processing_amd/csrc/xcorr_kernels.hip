@@ -31,6 +31,7 @@
 struct XcorrWs {
     std::map<int, float2*> twiddle;     // per FFT length n: n/2 values exp(-2 pi i k / n)
     std::map<int, float2*> chirp;       // per non-power-of-two length n: n chirp values, then the M filter values
+    std::map<int, float2*> circle;      // per length n with prime factors <= 13: n values exp(-2 pi i t / n)
     float* gauss = nullptr;             // 151 taps
     void* taps_mf = nullptr;            // the taps as matrix-core operands (xcorr_blur_mfma.h), built on first use
     hipStream_t side = nullptr;         // second stream: the two halves of a batch run side by side
@@ -47,6 +48,7 @@ void mis_xcorr_release(mis_ctx* ctx)
     if (!w) return;
     for (auto& kv : w->twiddle) (void)hipFree(kv.second);
     for (auto& kv : w->chirp) (void)hipFree(kv.second);
+    for (auto& kv : w->circle) (void)hipFree(kv.second);
     if (w->gauss) (void)hipFree(w->gauss);
     if (w->taps_mf) (void)hipFree(w->taps_mf);
     if (w->side) {
@@ -949,9 +951,11 @@ __global__ void xc_init_meta(int n, unsigned* minmax, unsigned long long* keys)
 // with the transform of the conj(c) filter precomputed in double (stored in the bit-reversed order
 // the DIF transform produces).  The 2-D transform is rows, transpose, rows, so that every 1-D
 // transform reads a contiguous sequence.  Slower than the power-of-two path (two transposes, natural
-// order throughout); it runs once per pair.
+// order throughout); it runs once per pair.  Lengths whose prime factors are all <= 13 skip the chirp:
+// a mixed-radix transform of the length itself (xcorr_smooth_dft.h).
 // ---------------------------------------------------------------------------------------------
-struct XgDft { int n, M, logM, pow2; const float2* chirp; const float2* filt; const float2* tw; };
+#include "xcorr_smooth_dft.h"
+struct XgDft { int n, M, logM, pow2, smooth; const float2* chirp; const float2* filt; const float2* tw; XsPlan xs; };
 
 // In-place DFT of sequences of length d.n.  Sequence r lives at data + (r / per_batch) * batch_stride
 // + (r % per_batch) * n.  inverse != 0: unnormalised backward transform (conjugate, forward, conjugate).
@@ -1045,32 +1049,42 @@ __global__ __launch_bounds__(256) void xg_transpose(const float2* __restrict__ i
         if (c0 + j < cols && r0 + tx < rows) dst[(size_t)(c0 + j) * rows + r0 + tx] = tile[tx][j];
 }
 
-// tiles of both images as complex rasters, zero outside the bounding box (image3.cpp:322-328)
+// both tiles as ONE complex raster z = a + i b, zero outside the bounding boxes (image3.cpp:322-328); tile t at spec + t * 2N
 __global__ __launch_bounds__(256) void xg_load_tiles(XcImage im, const mis_rect* __restrict__ r1,
                                                      const mis_rect* __restrict__ r2, int tile0, int w, int h,
                                                      float2* __restrict__ spec)
 {
-    const int t = blockIdx.z >> 1, side = blockIdx.z & 1, ry = blockIdx.y;
+    const int t = blockIdx.z, ry = blockIdx.y;
     const int rx = blockIdx.x * 256 + threadIdx.x;
     if (rx >= w) return;
-    const mis_rect bb = side ? r2[tile0 + t] : r1[tile0 + t];
-    float v = 0.f;
-    if (rx < bb.width && ry < bb.height) {
-        const int sx = bb.minx + rx, sy = bb.miny + ry;
-        if (sx >= 0 && sx < im.iw && sy >= 0 && sy < im.ih) v = load_px(im.img[side], im.dtype, im.stride, sx, sy);
+    float v[2];
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const mis_rect bb = side ? r2[tile0 + t] : r1[tile0 + t];
+        v[side] = 0.f;
+        if (rx < bb.width && ry < bb.height) {
+            const int sx = bb.minx + rx, sy = bb.miny + ry;
+            if (sx >= 0 && sx < im.iw && sy >= 0 && sy < im.ih) v[side] = load_px(im.img[side], im.dtype, im.stride, sx, sy);
+        }
     }
-    spec[((size_t)blockIdx.z * h + ry) * w + rx] = make_float2(v, 0.f);
+    spec[((size_t)t * 2 * h + ry) * w + rx] = make_float2(v[0], v[1]);
 }
 
-// a <- (a s)(conj(b s)) for the two spectra of every tile (image3.cpp:331-334, 392-394)
-__global__ __launch_bounds__(256) void xg_product(float2* __restrict__ spec, size_t N, float scale)
+// (A s) conj(B s) of the two real tiles (image3.cpp:331-334, 392-394) from the transform Z of a + i b, natural order,
+// stored transposed (rows = kx): A[k] = (Z[k] + conj(Z[-k])) / 2, B[k] = (Z[k] - conj(Z[-k])) / (2i).  Reads the first
+// plane of a tile (spec + t * 2N) and writes the second (every element is also some other element's mirror).
+__global__ __launch_bounds__(256) void xg_product(float2* __restrict__ spec, int w, int h, float scale)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    float2* sa = spec + (size_t)blockIdx.y * 2 * N;
-    float2 a = sa[i], b = sa[N + i];
-    a.x *= scale; a.y *= scale; b.x *= scale; b.y *= scale;
-    sa[i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    const int ky = blockIdx.x * 256 + threadIdx.x, kx = blockIdx.y;
+    if (ky >= h) return;
+    const size_t N = (size_t)w * h;
+    float2* sz = spec + (size_t)blockIdx.z * 2 * N;
+    const int mx = kx ? w - kx : 0, my = ky ? h - ky : 0;
+    const float2 zk = sz[(size_t)kx * h + ky], zm = sz[(size_t)mx * h + my];
+    const float hs = 0.5f * scale;
+    const float2 a = make_float2((zk.x + zm.x) * hs, (zk.y - zm.y) * hs);
+    const float2 b = make_float2((zk.y + zm.y) * hs, (zm.x - zk.x) * hs);
+    sz[N + (size_t)kx * h + ky] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
 
 // |c| / sqrt(N) and the tile extrema (image3.cpp:401-411), as in xc_rows_inv_abs
@@ -1175,12 +1189,31 @@ struct XcPlan { int w, h, logw, logh, RBw, CB; bool general; };
 static int get_dft(mis_ctx* ctx, int n, XgDft* d)
 {
     XcorrWs* w = ctx->xc;
-    d->n = n; d->chirp = nullptr; d->filt = nullptr;
+    d->n = n; d->chirp = nullptr; d->filt = nullptr; d->smooth = 0;
     if (is_pow2(n)) {
         d->pow2 = 1; d->M = n; d->logM = ilog2(n);
         return get_twiddle(ctx, n, &d->tw);
     }
     d->pow2 = 0;
+    // MISTEREO_XG_CHIRP=1 keeps the chirp-z transform for every length (comparison runs)
+    static const bool chirp_only = [] { const char* e = getenv("MISTEREO_XG_CHIRP"); return e && e[0] == '1'; }();
+    if (!chirp_only && xs_factor(n, &d->xs)) {
+        auto ci = w->circle.find(n);
+        if (ci == w->circle.end()) {
+            std::vector<float2> hc((size_t)n);
+            for (int t = 0; t < n; t++) {
+                const double a = -2.0 * M_PI * (double)t / (double)n;
+                hc[t] = make_float2((float)cos(a), (float)sin(a));
+            }
+            float2* dc = nullptr;
+            MIS_HIP(ctx, hipMalloc((void**)&dc, hc.size() * sizeof(float2)));
+            MIS_HIP(ctx, hipMemcpyAsync(dc, hc.data(), hc.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+            MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ci = w->circle.emplace(n, dc).first;
+        }
+        d->smooth = 1; d->xs.circle = ci->second; d->M = n; d->logM = 0; d->tw = nullptr;
+        return MIS_OK;
+    }
     d->M = 1; while (d->M < 2 * n - 1) d->M <<= 1;
     d->logM = ilog2(d->M);
     int rc = get_twiddle(ctx, d->M, &d->tw); if (rc) return rc;
@@ -1235,6 +1268,19 @@ static int get_dft(mis_ctx* ctx, int n, XgDft* d)
 
 static int launch_dft(mis_ctx* ctx, float2* data, const XgDft& d, int nseq, int per_batch, size_t batch_stride, int inverse)
 {
+    if (d.smooth) {
+        const size_t shs = ((size_t)d.n + d.n / 8 + 1) * sizeof(float2);
+        const dim3 g((unsigned)nseq);
+#define XS_LAUNCH(NTV)                                                                                              \
+    do {                                                                                                            \
+        if (shs > 64 * 1024)                                                                                        \
+            MIS_HIP(ctx, hipFuncSetAttribute((const void*)xs_dft_rows<NTV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs)); \
+        hipLaunchKernelGGL((xs_dft_rows<NTV, true>), g, dim3(NTV), shs, ctx->stream, data, d.xs, per_batch, batch_stride, inverse);       \
+    } while (0)
+        if (d.n > 4096) XS_LAUNCH(1024); else if (d.n > 2048) XS_LAUNCH(512); else XS_LAUNCH(256);
+#undef XS_LAUNCH
+        return MIS_OK;
+    }
     // padded LDS layout (see xp) whenever it fits
     const bool pad = (d.M % 8 == 0) && ((size_t)d.M + d.M / 8) * sizeof(float2) <= 160 * 1024;
     const size_t sh = ((size_t)d.M + (pad ? d.M / 8 : 0)) * sizeof(float2);
@@ -1453,13 +1499,13 @@ static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1
         im.img[1] = band ? ctx->band_img[1][band - 1] : ctx->img[1];
         im.dtype = ctx->dtype; im.iw = ctx->width; im.ih = ctx->height; im.stride = ctx->stride;
         if (band) hipLaunchKernelGGL(xc_reset_minmax, dim3((nt + 255) / 256), dim3(256), 0, s, nt, minmax);
-        hipLaunchKernelGGL(xg_load_tiles, dim3((w + 255) / 256, h, 2 * nt), dim3(256), 0, s, im, d_r1, d_r2, tile0, w, h, spec);
-        rc = launch_dft(ctx, spec, dw, 2 * nt * h, 2 * nt * h, 0, 0); if (rc) return rc;
-        hipLaunchKernelGGL(xg_transpose, dim3(tgrid.x, tgrid.y, 2 * nt), dim3(256), 0, s, spec, specT, h, w, N, N);
-        rc = launch_dft(ctx, specT, dh, 2 * nt * w, 2 * nt * w, 0, 0); if (rc) return rc;
-        hipLaunchKernelGGL(xg_product, dim3((unsigned)((N + 255) / 256), nt), dim3(256), 0, s, specT, N, scale);
-        rc = launch_dft(ctx, specT, dh, nt * w, w, 2 * N, 1); if (rc) return rc;
-        hipLaunchKernelGGL(xg_transpose, dim3(tgridT.x, tgridT.y, nt), dim3(256), 0, s, specT, spec, w, h, 2 * N, 2 * N);
+        hipLaunchKernelGGL(xg_load_tiles, dim3((w + 255) / 256, h, nt), dim3(256), 0, s, im, d_r1, d_r2, tile0, w, h, spec);
+        rc = launch_dft(ctx, spec, dw, nt * h, h, 2 * N, 0); if (rc) return rc;
+        hipLaunchKernelGGL(xg_transpose, dim3(tgrid.x, tgrid.y, nt), dim3(256), 0, s, spec, specT, h, w, 2 * N, 2 * N);
+        rc = launch_dft(ctx, specT, dh, nt * w, w, 2 * N, 0); if (rc) return rc;
+        hipLaunchKernelGGL(xg_product, dim3((h + 255) / 256, w, nt), dim3(256), 0, s, specT, w, h, scale);
+        rc = launch_dft(ctx, specT + N, dh, nt * w, w, 2 * N, 1); if (rc) return rc;
+        hipLaunchKernelGGL(xg_transpose, dim3(tgridT.x, tgridT.y, nt), dim3(256), 0, s, specT + N, spec, w, h, 2 * N, 2 * N);
         rc = launch_dft(ctx, spec, dw, nt * h, h, 2 * N, 1); if (rc) return rc;
         hipLaunchKernelGGL(xg_abs_minmax, dim3((unsigned)((N + 256 * XG_ABS_PER_THREAD - 1) / (256 * XG_ABS_PER_THREAD)), nt), dim3(256), 0, s, spec, N, scale, surf, minmax);
         if (nbands > 1)

@@ -40,6 +40,16 @@ class Leaf(C.Structure):
                 ("peak", C.c_float)]
 
 
+def _leaf_records(leaves, n):
+    """The first n records of a Leaf array as tuples (minx, miny, w, h, total_dx, total_dy, u1, v1, u2, v2, peak); read
+    through one numpy view of the array (a record is ten int32 and one float32) instead of one ctypes access per field."""
+    if n <= 0:
+        return []
+    a = np.frombuffer(leaves, dtype=np.int32, count=n * 11).reshape(n, 11)
+    peaks = a[:, 10].copy().view(np.float32).tolist()
+    return [tuple(i) + (p,) for i, p in zip(a[:, :10].tolist(), peaks)]
+
+
 class MisError(RuntimeError):
     def __init__(self, code, msg):
         RuntimeError.__init__(self, "libmistereo error %d: %s" % (code, msg))
@@ -361,9 +371,7 @@ class Group:
         self._check(self._lib.mis_group_disparity_map(self._h, w, h, min_size, leaves, max_leaves, C.byref(n), C.byref(nt)))
         if n.value > max_leaves:
             return self.disparity_map(min_size, n.value)
-        recs = [(l.bbox1.minx, l.bbox1.miny, l.bbox1.width, l.bbox1.height, l.total_dx, l.total_dy,
-                 l.u1, l.v1, l.u2, l.v2, l.peak) for l in leaves[:min(n.value, max_leaves)]]
-        return recs, nt.value
+        return _leaf_records(leaves, min(n.value, max_leaves)), nt.value
 
     def ncc_dense(self, left, right, window, dmin, dmax, want_idisp=True, want_peak2=False, out=None):
         """Dense NCC of a host pair, row strips over the group's devices; same result as Context.ncc_dense.
@@ -624,9 +632,7 @@ class Context:
             self._check(self._lib.mis_disparity_map(self._h, w, h, min_size, leaves, max_leaves, C.byref(n), C.byref(nt)))
         if n.value > max_leaves:                    # same answer in a buffer that holds them all
             return self.disparity_map(min_size, n.value)
-        recs = [(l.bbox1.minx, l.bbox1.miny, l.bbox1.width, l.bbox1.height, l.total_dx, l.total_dy,
-                 l.u1, l.v1, l.u2, l.v2, l.peak) for l in leaves[:min(n.value, max_leaves)]]
-        return recs, nt.value
+        return _leaf_records(leaves, min(n.value, max_leaves)), nt.value
 
     # ---- triangulation ----
     def calculate_xyz(self, cam1, cam2, pts):

@@ -154,7 +154,8 @@ def test_large_tile_2048(ctx):
 ])
 def test_find_offset_general_sizes(ctx, w, h, dx, dy):
     """Tile sides that are not powers of two (the first level of image3.cpp's recursion works on the
-    whole rasters): chirp-z row transforms against the oracle's mixed radix-2 / Bluestein FFT."""
+    whole rasters): mixed-radix row transforms (sides whose prime factors are all <= 13) and chirp-z ones
+    (127, 101, ...) against the oracle's mixed radix-2 / Bluestein FFT."""
     img1, img2 = _pair(h, w, dx, dy, 300 + w)
     ctx.upload_pair(img1, img2)
     peak, ox, oy = ctx.find_offset((0, 0, w, h), (0, 0, w, h), w, h)
@@ -168,9 +169,10 @@ def test_find_offset_general_sizes(ctx, w, h, dx, dy):
     assert np.abs(dog - ref["dog"]).max() <= 1e-4
 
 
-def test_general_size_large_frame(ctx):
-    """A 3000 x 2000 frame as one tile (transform lengths 8192 and 4096 internally)."""
-    w, h = 3000, 2000
+@pytest.mark.parametrize("w,h", [(3000, 2000), (2006, 1511)])
+def test_general_size_large_frame(ctx, w, h):
+    """A whole frame as one tile: 3000 x 2000 (2^3 3 5^3 and 2^4 5^3: mixed-radix transforms of the lengths themselves)
+    and 2006 x 1511 (2 17 59 and a prime: chirp-z transforms of lengths 4096)."""
     img1, img2 = _pair(h, w, -140, 77, 12)
     ctx.upload_pair(img1, img2)
     peak, ox, oy = ctx.find_offset((0, 0, w, h), (0, 0, w, h), w, h)
@@ -184,6 +186,26 @@ def test_fft2d_forward_general_sizes(ctx):
         got = ctx.fft2d_forward(img)
         want = np.fft.fft2(img.astype(np.float64)) / np.sqrt(shape[0] * shape[1])
         assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 2e-5, shape
+
+
+@pytest.mark.parametrize("shape", [
+    (6, 8000),        # 8 8 5 5 5: five passes, 1024 threads, eight elements per thread
+    (3, 6000),        # 8 2 3 5 5 5
+    (1001, 210),      # 7 11 13 and 2 3 5 7: every odd radix
+    (4, 8190),        # 2 3^2 5 7 13: the longest non-power-of-two sequences take 1024 threads with a ragged last round
+    (13, 6561),       # 3^8: eight passes of the smallest odd radix
+    (12, 4100),       # 4 5 5 41: a factor above 13 sends the whole length through the chirp
+    (22, 2 * 2 * 2 * 2 * 11 * 13),
+    (5, 3),
+])
+def test_fft2d_forward_mixed_radix_lengths(ctx, shape):
+    """Lengths whose prime factors are all <= 13 are transformed directly (radices 8, 4, 2, 3, 5, 7, 11, 13 in LDS)."""
+    rng = np.random.default_rng(shape[1])
+    img = rng.integers(0, 256, shape).astype(np.uint8)
+    got = ctx.fft2d_forward(img)
+    want = np.fft.fft2(img.astype(np.float64)) / np.sqrt(shape[0] * shape[1])
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 2e-5, shape
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), shape
 
 
 def test_xcorr_surface_u8_odd_size(ctx):
