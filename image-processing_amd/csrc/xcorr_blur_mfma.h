@@ -211,3 +211,183 @@ __global__ __launch_bounds__(512) void xc_colblur_argmax_mf(int w, int h, int SW
     }
     tile_commit_key(keys, t, best);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Tiles of 32 or 64 samples a side (the last levels of the recursion, thousands of tiles each): with BORDER_REFLECT_101 the
+// 151 taps fold onto the L samples of a line, so the filter along a line is a product with a fixed L x L matrix,
+// F[n][k] = sum of the taps g[j] with reflect101(n + j - 75, L) == k, and the whole blur of a tile is F_h * X * F_w^T: two
+// small products, no padded lines, no LDS.  One wavefront owns the 32 columns `bx` of a tile: rows pass Y = X F_w^T for its
+// columns (the A operand is read straight from the surface: 8 consecutive floats of a row per lane and step), columns pass
+// Z = F_h Y with Y taken from the accumulators as the B operand.  A lane's accumulators of a 32 x 32 block hold rows
+// 8 (i >> 2) + 4 (lane >> 5) + (i & 3) of column lane & 31, the B operand of step s wants eight K indices per lane: the
+// columns pass simply sums over K in the order the accumulators have (K index of step s, element e of a lane:
+// 32 (s >> 1) + 8 (2 (s & 1) + (e >> 2)) + 4 (lane >> 5) + (e & 3)), and the table of F_h is laid out to match.
+// Same splitting into f16 halves, same scaling and the same outputs as the two kernels above together (normalised surface
+// back into `surf`, DoG, first maximum), minus the row-filtered plane that nothing else reads.
+// Table of a length L (NB = L / 32 blocks, KS = L / 16 steps), vectors of 8 halves per lane:
+//   rows operand     [(s * NB + bx) * 2 + hl][lane]   F[32 bx + (lane & 31)][16 s + 8 (lane >> 5) + e] * 128
+//   columns operand  [(by * KS + s) * 2 + hl][lane]   F[32 by + (lane & 31)][K index above] * 128, after the rows operand
+// ---------------------------------------------------------------------------------------------------------------------
+static inline size_t xb_small_vectors(int L) { return (size_t)2 * (L / 16) * (L / 32) * 2 * 64; }
+static inline bool xb_small_fits(int w, int h) { return (w == 32 || w == 64) && (h == 32 || h == 64); }
+
+// taps: the 151 float taps; out: xb_small_vectors(L) vectors of 8 halves (as raw 16-bit patterns via _Float16 on the host)
+static void xb_build_small(const float* taps, int L, _Float16* out)
+{
+    const int NB = L / 32, KS = L / 16;
+    std::vector<double> F((size_t)L * L, 0.0);
+    for (int n = 0; n < L; n++)
+        for (int j = 0; j < XC_GAUSS_K; j++) {
+            int p = n + j - XC_GAUSS_R;
+            while ((unsigned)p >= (unsigned)L) p = p < 0 ? -p : 2 * L - 2 - p;
+            F[(size_t)n * L + p] += (double)taps[j];
+        }
+    auto put = [&](size_t vec, int lane, int e, double v) {
+        const float f = (float)v * XB_TAPSCALE;
+        const _Float16 a = (_Float16)f;
+        out[((vec * 2 + 0) * 64 + lane) * 8 + e] = a;
+        out[((vec * 2 + 1) * 64 + lane) * 8 + e] = (_Float16)(f - (float)a);
+    };
+    const size_t cols0 = (size_t)KS * NB;          // first vector pair of the columns operand
+    for (int lane = 0; lane < 64; lane++) {
+        const int n = lane & 31, kg = lane >> 5;
+        for (int s = 0; s < KS; s++)
+            for (int b = 0; b < NB; b++)
+                for (int e = 0; e < 8; e++) {
+                    put((size_t)s * NB + b, lane, e, F[(size_t)(32 * b + n) * L + 16 * s + 8 * kg + e]);
+                    const int k = 32 * (s >> 1) + 8 * (2 * (s & 1) + (e >> 2)) + 4 * kg + (e & 3);
+                    put(cols0 + (size_t)b * KS + s, lane, e, F[(size_t)(32 * b + n) * L + k]);
+                }
+    }
+}
+
+__device__ __forceinline__ void xb_split8(const float (&v)[8], xb_half8& h, xb_half8& l)
+{
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const _Float16 a = (_Float16)v[e];
+        h[e] = a;
+        l[e] = (_Float16)(v[e] - (float)a);
+    }
+}
+
+// stages 4 and 5 of tiles of 32 NBW x 32 NBH samples: grid ceil(tiles * NBW / 4), 256 threads (four wavefronts; the
+// wavefronts of a tile share a workgroup).  tw: the table of the width, th: the table of the height.
+template <int NBW, int NBH>
+__global__ __launch_bounds__(256) void xc_blur_small_mf(int nt, const unsigned* __restrict__ minmax,
+                                                        const xb_half8* __restrict__ tw, const xb_half8* __restrict__ th,
+                                                        float* __restrict__ surf, float* __restrict__ dog_out,
+                                                        unsigned long long* __restrict__ keys, int pre)
+{
+    constexpr int W = 32 * NBW, H = 32 * NBH, KSW = 2 * NBW, KSH = 2 * NBH;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kg = lane >> 5;
+    const int wid = blockIdx.x * 4 + (tid >> 6);
+    const bool live = wid < nt * NBW;
+    const int t = live ? wid / NBW : 0, bx = wid % NBW;
+    float* st = surf + (size_t)t * W * H;
+    const float mn = __uint_as_float(minmax[2 * t]), mx = __uint_as_float(minmax[2 * t + 1]);
+    const double dmn = (double)mn, drange = (double)(mx - mn);
+    // the whole tile as A operands, normalised as the reference does (image3.cpp:414-416, in double, narrowed), before any
+    // wavefront of the tile writes normalised values back
+    xb_half8 ah[NBH][KSW], al[NBH][KSW];
+    if (live) {
+        float4 raw[NBH][KSW][2];
+#pragma unroll
+        for (int by = 0; by < NBH; by++)
+#pragma unroll
+            for (int s = 0; s < KSW; s++) {
+                const float4* p = (const float4*)(st + (size_t)(32 * by + n) * W + 16 * s + 8 * kg);
+                raw[by][s][0] = p[0]; raw[by][s][1] = p[1];
+            }
+#pragma unroll
+        for (int by = 0; by < NBH; by++)
+#pragma unroll
+            for (int s = 0; s < KSW; s++) {
+                float v[8] = { raw[by][s][0].x, raw[by][s][0].y, raw[by][s][0].z, raw[by][s][0].w,
+                               raw[by][s][1].x, raw[by][s][1].y, raw[by][s][1].z, raw[by][s][1].w };
+                if (!pre) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = (float)(((double)v[e] - dmn) / drange);
+                }
+                xb_split8(v, ah[by][s], al[by][s]);
+            }
+    }
+    __syncthreads();
+    if (!live) return;
+    // this wavefront's own columns in the accumulators' layout (nobody else writes them)
+    float own[NBH][16];
+#pragma unroll
+    for (int by = 0; by < NBH; by++)
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            own[by][i] = st[(size_t)(32 * by + 8 * (i >> 2) + 4 * kg + (i & 3)) * W + 32 * bx + n];
+    // rows pass
+    xb_f32x16 Y[NBH];
+    {
+        xb_half8 bh[KSW], bl[KSW];
+#pragma unroll
+        for (int s = 0; s < KSW; s++) {
+            bh[s] = tw[((size_t)(s * NBW + bx) * 2 + 0) * 64 + lane];
+            bl[s] = tw[((size_t)(s * NBW + bx) * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int by = 0; by < NBH; by++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) Y[by][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KSW; s++) {
+                Y[by] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[by][s], bh[s], Y[by], 0, 0, 0);
+                Y[by] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[by][s], bl[s], Y[by], 0, 0, 0);
+                Y[by] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[by][s], bh[s], Y[by], 0, 0, 0);
+            }
+        }
+    }
+    // the row-filtered columns as B operands of the columns pass
+    xb_half8 yh[KSH], yl[KSH];
+#pragma unroll
+    for (int s = 0; s < KSH; s++) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = Y[s >> 1][8 * (s & 1) + e] * (1.0f / XB_TAPSCALE);
+        xb_split8(v, yh[s], yl[s]);
+    }
+    const xb_half8* tc = th + (size_t)KSH * NBH * 2 * 64;
+    unsigned long long best = 0;
+#pragma unroll
+    for (int by = 0; by < NBH; by++) {
+        xb_f32x16 Z;
+#pragma unroll
+        for (int i = 0; i < 16; i++) Z[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KSH; s++) {
+            const xb_half8 fh = tc[((size_t)(by * KSH + s) * 2 + 0) * 64 + lane];
+            const xb_half8 fl = tc[((size_t)(by * KSH + s) * 2 + 1) * 64 + lane];
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, yh[s], Z, 0, 0, 0);
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, yl[s], Z, 0, 0, 0);
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, yh[s], Z, 0, 0, 0);
+        }
+        // the A operand's lines are the output rows: a lane's accumulators are rows of ITS column x again
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int y = 32 * by + 8 * (i >> 2) + 4 * kg + (i & 3), x = 32 * bx + n;
+            float xn = own[by][i];
+            if (!pre) {
+                xn = (float)(((double)xn - dmn) / drange);
+                st[(size_t)y * W + x] = xn;
+            }
+            const float d = __fsub_rn(xn, Z[i] * (1.0f / XB_TAPSCALE));
+            if (dog_out) dog_out[(size_t)t * W * H + (size_t)y * W + x] = d;
+            if (d > -1.0f) {
+                const unsigned long long k = argmax_key(d, (unsigned)(y * W + x));
+                best = k > best ? k : best;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o);
+        best = other > best ? other : best;
+    }
+    // one atomic per wavefront: the wavefronts of this workgroup belong to different tiles (tile_commit_key combines a
+    // workgroup, and its LDS slots of wavefronts that left above would hold whatever the last kernel wrote there)
+    if (lane == 0 && best) atomicMax(&keys[t], best);
+}

@@ -34,10 +34,13 @@ struct XcorrWs {
     std::map<int, float2*> circle;      // per length n with prime factors <= 13: n values exp(-2 pi i t / n)
     float* gauss = nullptr;             // 151 taps
     void* taps_mf = nullptr;            // the taps as matrix-core operands (xcorr_blur_mfma.h), built on first use
+    std::map<int, void*> taps_small;    // per tile side 32 / 64: the folded filter matrix as matrix-core operands
     hipStream_t side = nullptr;         // second stream: the two halves of a batch run side by side
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* buf = nullptr; size_t buf_bytes = 0;      // spectra / surfaces of one batch of tiles
     void* meta = nullptr; size_t meta_bytes = 0;    // per-tile min/max, argmax keys, rects
+    void* io = nullptr; size_t io_bytes = 0;        // rectangles in, offsets out of a host call (mis_xcorr_tiles): kept between
+                                                    // calls, the recursion makes one call per tile size and level
     const float* last_surface = nullptr;            // normalised surfaces of the last batch (inspection)
     const float* last_abs = nullptr;                // |c| surfaces of the last batch (before normalisation)
 };
@@ -51,6 +54,7 @@ void mis_xcorr_release(mis_ctx* ctx)
     for (auto& kv : w->circle) (void)hipFree(kv.second);
     if (w->gauss) (void)hipFree(w->gauss);
     if (w->taps_mf) (void)hipFree(w->taps_mf);
+    for (auto& kv : w->taps_small) (void)hipFree(kv.second);
     if (w->side) {
         (void)hipStreamSynchronize(w->side);
         (void)hipEventDestroy(w->ev_fork); (void)hipEventDestroy(w->ev_join);
@@ -58,6 +62,7 @@ void mis_xcorr_release(mis_ctx* ctx)
     }
     if (w->buf) (void)hipFree(w->buf);
     if (w->meta) (void)hipFree(w->meta);
+    if (w->io) (void)hipFree(w->io);
     delete w;
     ctx->xc = nullptr;
 }
@@ -1331,9 +1336,35 @@ static bool blur_on_matrix_cores(int w, int h)
     return mf_env != 0 && xb_fits(w, h);
 }
 // the matrix-core operand table, built on the context's stream before any stage that reads it is enqueued
+// tiles of 32 / 64 samples a side take the folded filter (xc_blur_small_mf); MISTEREO_XC_SMALL=0 keeps the two general kernels
+static bool blur_small(int w, int h)
+{
+    static const int env = [] { const char* e = getenv("MISTEREO_XC_SMALL"); return e ? atoi(e) : 1; }();
+    return env != 0 && blur_on_matrix_cores(w, h) && xb_small_fits(w, h);
+}
+static int ensure_small_taps(mis_ctx* ctx, int L)
+{
+    XcorrWs* ws = ctx->xc;
+    if (ws->taps_small.count(L)) return MIS_OK;
+    float k[XC_GAUSS_K];
+    MIS_HIP(ctx, hipMemcpyAsync(k, ws->gauss, sizeof k, hipMemcpyDeviceToHost, ctx->stream));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<_Float16> host(xb_small_vectors(L) * 8);
+    xb_build_small(k, L, host.data());
+    void* d = nullptr;
+    MIS_HIP(ctx, hipMalloc(&d, host.size() * sizeof(_Float16)));
+    MIS_HIP(ctx, hipMemcpyAsync(d, host.data(), host.size() * sizeof(_Float16), hipMemcpyHostToDevice, ctx->stream));
+    MIS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ws->taps_small[L] = d;
+    return MIS_OK;
+}
 static int ensure_taps(mis_ctx* ctx, int w, int h)
 {
     XcorrWs* ws = ctx->xc;
+    if (blur_small(w, h)) {
+        int rc = ensure_small_taps(ctx, w); if (rc) return rc;
+        return ensure_small_taps(ctx, h);
+    }
     if (!blur_on_matrix_cores(w, h) || ws->taps_mf) return MIS_OK;
     MIS_HIP(ctx, hipMalloc(&ws->taps_mf, (size_t)2 * XB_KSTEPS * 64 * sizeof(xb_half8)));
     hipLaunchKernelGGL(xb_build_taps, dim3(1), dim3(64), 0, ctx->stream, ws->gauss, (xb_half8*)ws->taps_mf);
@@ -1344,6 +1375,17 @@ static int launch_blur_stages(mis_ctx* ctx, hipStream_t s, int w, int h, int nt,
                               float* dog_dbg, unsigned long long* keys)
 {
     XcorrWs* ws = ctx->xc;
+    if (blur_small(w, h)) {
+        const xb_half8* tw = (const xb_half8*)ws->taps_small[w];
+        const xb_half8* th = (const xb_half8*)ws->taps_small[h];
+        const int nbw = w / 32;
+        const dim3 g((unsigned)(((size_t)nt * nbw + 3) / 4));
+#define XB_SMALL(NBW, NBH) hipLaunchKernelGGL((xc_blur_small_mf<NBW, NBH>), g, dim3(256), 0, s, nt, minmax, tw, th, fsurf, dog_dbg, keys, pre ? 1 : 0)
+        if (w == 32 && h == 32) XB_SMALL(1, 1); else if (w == 64 && h == 32) XB_SMALL(2, 1);
+        else if (w == 32 && h == 64) XB_SMALL(1, 2); else XB_SMALL(2, 2);
+#undef XB_SMALL
+        return MIS_OK;
+    }
     if (blur_on_matrix_cores(w, h)) {
         const xb_half8* taps = (const xb_half8*)ws->taps_mf;
         const size_t sha = xb_lds_bytes(w), shb = xb_lds_bytes(h);
@@ -1633,11 +1675,13 @@ int mis_xcorr_tiles(mis_ctx* ctx, const mis_rect* r1, const mis_rect* r2, int n,
     if (n < 0 || (n > 0 && (!r1 || !r2 || !out))) return mis_fail(ctx, MIS_ERR_ARG, "tile correlation: NULL buffer");
     if (n == 0) return MIS_OK;
     MIS_HIP(ctx, hipSetDevice(ctx->device));
-    void* d = nullptr;
+    int rc = ensure_ws(ctx); if (rc) return rc;
+    XcorrWs* ws = ctx->xc;
     const size_t rb = (size_t)n * sizeof(mis_rect), ob = (size_t)n * sizeof(mis_offset);
-    MIS_HIP(ctx, hipMalloc(&d, 2 * rb + ob));
-    mis_rect* d1 = (mis_rect*)d; mis_rect* d2 = d1 + n; mis_offset* dout = (mis_offset*)(d2 + n);
-    int rc = MIS_OK;
+    size_t cap = 64 * 1024;                       // grows by doubling: every level of the recursion brings more tiles
+    while (cap < 2 * rb + ob) cap *= 2;
+    rc = mis_reserve(ctx, &ws->io, &ws->io_bytes, cap); if (rc) return rc;
+    mis_rect* d1 = (mis_rect*)ws->io; mis_rect* d2 = d1 + n; mis_offset* dout = (mis_offset*)(d2 + n);
     hipError_t e = hipMemcpyAsync(d1, r1, rb, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d2, r2, rb, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "tile correlation: upload failed: %s", hipGetErrorString(e));
@@ -1647,8 +1691,7 @@ int mis_xcorr_tiles(mis_ctx* ctx, const mis_rect* r1, const mis_rect* r2, int n,
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "tile correlation: download failed: %s", hipGetErrorString(e));
     }
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
+    (void)hipStreamSynchronize(ctx->stream);      // the staging buffer is free for the next call, also after a failure
     return rc;
 }
 
