@@ -65,6 +65,36 @@ def test_batched_tiles_with_padding_and_offsets(ctx):
         assert abs(got["peak"][k] - ref["peak"]) <= 1e-4 * max(abs(ref["peak"]), 1e-3) + 1e-5
 
 
+@pytest.mark.parametrize("tw,th", [(32, 32), (64, 32), (32, 64), (64, 64)])
+def test_batches_of_small_tiles(ctx, tw, th):
+    """Tiles of 32 / 64 samples a side take one fused kernel for both Gaussian passes (the reflected taps folded into an
+    L x L matrix), four wavefronts of different tiles per workgroup: a batch that does not fill its last workgroup, displaced
+    second boxes, one constant tile in the middle (max == min) and the DoG surface of a single tile, against the oracle."""
+    rng = np.random.default_rng(tw + 3 * th)
+    img1, img2 = _pair(300, 400, 3, -2, 77 + tw)
+    img1[100:100 + th, 200:200 + tw] = 9
+    img2[100:100 + th, 200:200 + tw] = 9
+    ctx.upload_pair(img1, img2)
+    r1, r2 = [], []
+    for k in range(13):
+        i, j = int(rng.integers(0, 400 - tw)), int(rng.integers(0, 300 - th))
+        ox, oy = (int(v) for v in rng.integers(-3, 4, 2))
+        r1.append((i, j, tw, th))
+        r2.append((min(max(i + ox, 0), 400 - tw), min(max(j + oy, 0), 300 - th), tw, th))
+    r1[6] = r2[6] = (200, 100, tw, th)                       # the constant tile
+    r1.append((5, 7, tw - 5, th - 3)); r2.append((6, 7, tw - 5, th - 3))       # zero-padded tile
+    got = ctx.find_offsets(r1, r2, tw, th)
+    for k, (a, b) in enumerate(zip(r1, r2)):
+        ref = oracle.find_offset(img1, img2, a, b, tw, th, precision=1)
+        assert (got["dx"][k], got["dy"][k]) == (ref["dx"], ref["dy"]), "tile %d" % k
+        assert abs(got["peak"][k] - ref["peak"]) <= 1e-4 * max(abs(ref["peak"]), 1e-3) + 1e-5
+    assert got["peak"][6] == -1.0
+    surf, dog = ctx.tile_surfaces(r1[0], r2[0], tw, th)
+    ref = oracle.find_offset(img1, img2, r1[0], r2[0], tw, th, precision=1, want_surface=True, want_dog=True)
+    assert np.abs(surf - ref["surface"]).max() <= 3e-5
+    assert np.abs(dog - ref["dog"]).max() <= 1e-4
+
+
 def test_rectangular_tile_and_u16_f32(ctx):
     for dtype in (np.uint16, np.float32):
         base1, base2 = _pair(64, 256, -17, 4, 3, np.uint16)
