@@ -41,6 +41,7 @@ struct XcorrWs {
     void* meta = nullptr; size_t meta_bytes = 0;    // per-tile min/max, argmax keys, rects
     void* io = nullptr; size_t io_bytes = 0;        // rectangles in, offsets out of a host call (mis_xcorr_tiles): kept between
                                                     // calls, the recursion makes one call per tile size and level
+    void* io_host = nullptr; size_t io_host_bytes = 0;   // the same, page-locked, on the host: one copy up, one copy down
     const float* last_surface = nullptr;            // normalised surfaces of the last batch (inspection)
     const float* last_abs = nullptr;                // |c| surfaces of the last batch (before normalisation)
 };
@@ -63,6 +64,7 @@ void mis_xcorr_release(mis_ctx* ctx)
     if (w->buf) (void)hipFree(w->buf);
     if (w->meta) (void)hipFree(w->meta);
     if (w->io) (void)hipFree(w->io);
+    if (w->io_host) (void)hipHostFree(w->io_host);
     delete w;
     ctx->xc = nullptr;
 }
@@ -1681,15 +1683,24 @@ int mis_xcorr_tiles(mis_ctx* ctx, const mis_rect* r1, const mis_rect* r2, int n,
     size_t cap = 64 * 1024;                       // grows by doubling: every level of the recursion brings more tiles
     while (cap < 2 * rb + ob) cap *= 2;
     rc = mis_reserve(ctx, &ws->io, &ws->io_bytes, cap); if (rc) return rc;
+    if (ws->io_host_bytes < cap) {
+        if (ws->io_host) { (void)hipHostFree(ws->io_host); ws->io_host = nullptr; ws->io_host_bytes = 0; }
+        MIS_HIP(ctx, hipHostMalloc(&ws->io_host, cap, hipHostMallocDefault));
+        ws->io_host_bytes = cap;
+    }
     mis_rect* d1 = (mis_rect*)ws->io; mis_rect* d2 = d1 + n; mis_offset* dout = (mis_offset*)(d2 + n);
-    hipError_t e = hipMemcpyAsync(d1, r1, rb, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d2, r2, rb, hipMemcpyHostToDevice, ctx->stream);
+    // both rectangle lists through the page-locked buffer in ONE copy, the offsets back in one: pageable copies of a few
+    // kilobytes cost a staging step each, and the recursion makes a call per tile size and level
+    char* hb = (char*)ws->io_host;
+    memcpy(hb, r1, rb); memcpy(hb + rb, r2, rb);
+    hipError_t e = hipMemcpyAsync(d1, hb, 2 * rb, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "tile correlation: upload failed: %s", hipGetErrorString(e));
     if (!rc) rc = xcorr_run(ctx, d1, d2, n, tile_w, tile_h, dout, nullptr);
     if (!rc) {
-        e = hipMemcpyAsync(out, dout, ob, hipMemcpyDeviceToHost, ctx->stream);
+        e = hipMemcpyAsync(hb + 2 * rb, dout, ob, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = mis_fail(ctx, MIS_ERR_DEVICE, "tile correlation: download failed: %s", hipGetErrorString(e));
+        else memcpy(out, hb + 2 * rb, ob);
     }
     (void)hipStreamSynchronize(ctx->stream);      // the staging buffer is free for the next call, also after a failure
     return rc;
