@@ -20,9 +20,16 @@
 
 namespace {
 
+// A tile of the current level and its place in the tree of all tiles evaluated so far.  The children of a tile are
+// appended to the tree together, in the reference's loop order, so the depth-first visiting order of the reference's
+// recursion is a walk over (first_child, n_children) at the end: no per-tile path, no sort.
 struct Node {
     mis_rect b1, b2;
-    std::vector<uint32_t> path;   // child indices from the root: depth-first order == lexicographic order
+    int tree;                     // index into the tree
+};
+struct TreeNode {
+    int first_child = -1, n_children = 0;
+    int leaf = -1;                // index into the leaves (a tile is a leaf or has children)
 };
 
 int pow2_floor(int v) { int r = 0; while (v >>= 1) r++; return 1 << r; }
@@ -47,9 +54,12 @@ int mis_disparity_map_with2(const MisTileEval& eval, int width1, int height1, in
     std::vector<Node> level(1);
     level[0].b1 = mis_rect{ 0, 0, width1, height1 };                     // image3.cpp:1001-1006
     level[0].b2 = mis_rect{ 0, 0, width2, height2 };
-    struct Leaf { mis_leaf l; std::vector<uint32_t> path; };
-    std::vector<Leaf> out;
+    level[0].tree = 0;
+    std::vector<TreeNode> tree(1);
+    std::vector<mis_leaf> out;
     int tiles = 0;
+    std::vector<mis_rect> r1, r2;
+    std::vector<mis_offset> o;
 
     while (!level.empty()) {
         // group the level's tiles by transform size (max of the two boxes, image3.cpp:687-688)
@@ -61,9 +71,9 @@ int mis_disparity_map_with2(const MisTileEval& eval, int width1, int height1, in
         std::vector<mis_offset> off(level.size());
         for (auto& kv : by_size) {
             const int w = kv.first.first, h = kv.first.second;
-            std::vector<mis_rect> r1, r2;
+            r1.clear(); r2.clear();
             for (int i : kv.second) { r1.push_back(level[i].b1); r2.push_back(level[i].b2); }
-            std::vector<mis_offset> o(r1.size());
+            o.resize(r1.size());
             int rc = eval(r1.data(), r2.data(), (int)r1.size(), w, h, o.data());
             if (rc) return rc;
             for (size_t k = 0; k < kv.second.size(); k++) off[kv.second[k]] = o[k];
@@ -71,6 +81,7 @@ int mis_disparity_map_with2(const MisTileEval& eval, int width1, int height1, in
         }
 
         std::vector<Node> next;
+        next.reserve(level.size() * 4);
         for (int i = 0; i < (int)level.size(); i++) {
             const Node& n = level[i];
             const mis_rect bbox1 = n.b1, bbox2 = n.b2;
@@ -98,7 +109,7 @@ int mis_disparity_map_with2(const MisTileEval& eval, int width1, int height1, in
 
             if (overlap.width > 2 * min_size && overlap.height > 2 * min_size && max > 0.75) {   // :751
                 const int dim = pow2_floor(std::min(overlap.width, overlap.height)) / 2;          // :754-761
-                uint32_t child = 0;
+                tree[n.tree].first_child = (int)tree.size();
                 for (int j = 0; j < overlap.height; j += dim) {                                  // :764-774
                     const int jj = j + dim > overlap.height ? overlap.height - dim : j;
                     for (int ii0 = 0; ii0 < overlap.width; ii0 += dim) {
@@ -106,30 +117,38 @@ int mis_disparity_map_with2(const MisTileEval& eval, int width1, int height1, in
                         Node c;
                         c.b1 = mis_rect{ overlap.minx + ii, overlap.miny + jj, dim, dim };
                         c.b2 = mis_rect{ overlap2.minx + ii, overlap2.miny + jj, dim, dim };
-                        c.path = n.path;
-                        c.path.push_back(child++);
-                        next.push_back(std::move(c));
+                        c.tree = (int)tree.size();
+                        tree.emplace_back();
+                        next.push_back(c);
                     }
                 }
+                tree[n.tree].n_children = (int)tree.size() - tree[n.tree].first_child;
             } else {                                                                              // :812-861
-                Leaf lf;
-                lf.l.bbox1 = bbox1;
-                lf.l.total_dx = total_offset_x; lf.l.total_dy = total_offset_y;
-                lf.l.u1 = overlap.minx + overlap.width / 2;
-                lf.l.v1 = overlap.miny + overlap.height / 2;
-                lf.l.u2 = overlap2.minx + overlap2.width / 2;
-                lf.l.v2 = overlap2.miny + overlap2.height / 2;
-                lf.l.peak = max;
-                lf.path = n.path;
-                out.push_back(std::move(lf));
+                mis_leaf lf;
+                lf.bbox1 = bbox1;
+                lf.total_dx = total_offset_x; lf.total_dy = total_offset_y;
+                lf.u1 = overlap.minx + overlap.width / 2;
+                lf.v1 = overlap.miny + overlap.height / 2;
+                lf.u2 = overlap2.minx + overlap2.width / 2;
+                lf.v2 = overlap2.miny + overlap2.height / 2;
+                lf.peak = max;
+                tree[n.tree].leaf = (int)out.size();
+                out.push_back(lf);
             }
         }
         level.swap(next);
     }
-    std::sort(out.begin(), out.end(), [](const Leaf& a, const Leaf& b) { return a.path < b.path; });
     *n_leaves = (int)out.size();
     if (n_tiles) *n_tiles = tiles;
-    for (int i = 0; i < (int)out.size() && i < max_leaves; i++) leaves[i] = out[i].l;
+    // the leaves in the reference's depth-first visiting order: children pushed in reverse, so the first one is visited first
+    std::vector<int> stack(1, 0);
+    int emitted = 0;
+    while (!stack.empty() && emitted < max_leaves) {
+        const TreeNode t = tree[stack.back()];
+        stack.pop_back();
+        if (t.leaf >= 0) { leaves[emitted++] = out[t.leaf]; continue; }
+        for (int c = t.n_children - 1; c >= 0; c--) stack.push_back(t.first_child + c);
+    }
     return MIS_OK;
     } catch (...) {
         return MIS_ERR_STATE;
