@@ -213,6 +213,152 @@ __global__ __launch_bounds__(512) void xc_colblur_argmax_mf(int w, int h, int SW
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Lines longer than the LDS image above holds (tiles of 2048 and up), and even sides that are not multiples of 32 (the
+// whole rasters of the recursion's first level): the same products on SEGMENTS of XB_SEG outputs of a line, each with its
+// 75 + 75 neighbours (reflected at the line's ends only).  A segment's neighbours belong to other workgroups, so the rows
+// pass cannot normalise the surface in place as xc_norm_rowblur_mf does: it reads the raw surface, normalises on the fly
+// (a product with the reciprocal of the range in double: the filter's operands keep 22 bits anyway) and writes only the
+// row-filtered plane; the columns pass, which reads every sample of the surface exactly once for the DoG, normalises it
+// there as the reference does (a division in double, narrowed) and writes it back.
+// Partial blocks (rows, columns or outputs beyond the tile) are clamped on the way in and masked on the way out.
+// ---------------------------------------------------------------------------------------------------------------------
+#define XB_SEG 256
+#define XB_SEG_STRIDE 424       // xb_line_stride(XB_SEG): 256 + 160 samples, rounded up to 8 mod 16
+static inline size_t xb_seg_lds_bytes() { return (size_t)2 * 32 * XB_SEG_STRIDE * sizeof(_Float16); }
+static inline bool xb_seg_fits(int w, int h) { return w % 4 == 0 && h % 2 == 0 && w >= 32 && h >= 32; }
+
+// rows pass: grid (ceil(h / 32), tiles, ceil(w / XB_SEG)), 512 threads
+__global__ __launch_bounds__(512) void xc_rowblur_seg_mf(int w, int h, const unsigned* __restrict__ minmax,
+                                                         const xb_half8* __restrict__ taps,
+                                                         const float* __restrict__ surf, float* __restrict__ tmp, int pre)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char xb_smem[];
+    constexpr int SW = XB_SEG_STRIDE;
+    constexpr int LW = XB_SEG + 160;
+    _Float16* hi = (_Float16*)xb_smem;
+    _Float16* lo = hi + 32 * SW;
+    const int t = blockIdx.y, y0 = 32 * blockIdx.x, x0 = XB_SEG * blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float mn = __uint_as_float(minmax[2 * t]), mx = __uint_as_float(minmax[2 * t + 1]);
+    const double dmn = (double)mn, rrange = 1.0 / (double)(mx - mn);
+    xb_half8 bh[XB_KSTEPS], bl[XB_KSTEPS];
+    xb_taps(taps, lane, bh, bl);
+    const float* st = surf + (size_t)t * h * w;
+    const int nout = min(XB_SEG, w - x0);           // outputs of this segment
+    const int nvalid = nout + 2 * XC_GAUSS_R;       // samples of the line image that exist; zeros behind them
+    for (int idx0 = tid; idx0 < 32 * LW; idx0 += 8 * 512) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = min(idx0 + 512 * k, 32 * LW - 1);
+            const int r = idx / LW, i = idx - r * LW;
+            const int sx = reflect101(x0 + min(i, nvalid - 1) - XC_GAUSS_R, w);
+            v[k] = st[(size_t)min(y0 + r, h - 1) * w + sx];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = idx0 + 512 * k;
+            if (idx >= 32 * LW) continue;
+            const int r = idx / LW, i = idx - r * LW;
+            float o = v[k];
+            if (!pre) o = (float)(((double)o - dmn) * rrange);
+            if (i >= nvalid) o = 0.f;
+            const _Float16 a = (_Float16)o;
+            hi[r * SW + i] = a;
+            lo[r * SW + i] = (_Float16)(o - (float)a);
+        }
+    }
+    __syncthreads();
+    float* tblk = tmp + (size_t)t * h * w;
+    const int n = lane & 31, kg = lane >> 5;
+    for (int b = wv; 32 * b < nout; b += 8) {
+        const xb_f32x16 acc = xb_block(hi, lo, SW, 32 * b, lane, bh, bl);
+        const int x = x0 + 32 * b + n;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int row = y0 + 8 * (i >> 2) + 4 * kg + (i & 3);
+            if (row < h && x < w) tblk[(size_t)row * w + x] = acc[i] * (1.0f / XB_TAPSCALE);
+        }
+    }
+}
+
+// columns pass: grid (ceil(w / 32), tiles, ceil(h / XB_SEG)), 512 threads; w a multiple of 4
+__global__ __launch_bounds__(512) void xc_colblur_seg_mf(int w, int h, const unsigned* __restrict__ minmax,
+                                                         const xb_half8* __restrict__ taps, float* __restrict__ surf,
+                                                         const float* __restrict__ tmp, float* __restrict__ dog_out,
+                                                         unsigned long long* __restrict__ keys, int pre)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char xb_smem[];
+    constexpr int SW = XB_SEG_STRIDE;
+    constexpr int LW = XB_SEG + 160;
+    _Float16* hi = (_Float16*)xb_smem;
+    _Float16* lo = hi + 32 * SW;
+    const int t = blockIdx.y, x0 = 32 * blockIdx.x, y0 = XB_SEG * blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float mn = __uint_as_float(minmax[2 * t]), mx = __uint_as_float(minmax[2 * t + 1]);
+    const double dmn = (double)mn, drange = (double)(mx - mn);
+    xb_half8 bh[XB_KSTEPS], bl[XB_KSTEPS];
+    xb_taps(taps, lane, bh, bl);
+    const float* tt = tmp + (size_t)t * h * w;
+    const int nout = min(XB_SEG, h - y0);
+    const int nvalid = nout + 2 * XC_GAUSS_R;
+    // the columns as lines: sample i of line c is row reflect(y0 + i - 75) of column x0 + c; 16 samples per pass
+    const int c = tid & 31, ri = tid >> 5;
+    const int xc = min(x0 + c, w - 1);
+    for (int q0 = 0; q0 < LW / 16; q0 += 13) {      // LW / 16 = 26 passes, thirteen in flight
+        float v[13];
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            const int i = min(16 * (q0 + k) + ri, nvalid - 1);
+            v[k] = tt[(size_t)reflect101(y0 + i - XC_GAUSS_R, h) * w + xc];
+        }
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            const int i = 16 * (q0 + k) + ri;
+            const float o = i < nvalid ? v[k] : 0.f;
+            const _Float16 a = (_Float16)o;
+            hi[c * SW + i] = a;
+            lo[c * SW + i] = (_Float16)(o - (float)a);
+        }
+    }
+    __syncthreads();
+    const int n = lane & 31, kg = lane >> 5;
+    float* st = surf + (size_t)t * h * w;
+    unsigned long long best = 0;
+    for (int b = wv; 32 * b < nout; b += 8) {
+        const xb_f32x16 acc = xb_block(hi, lo, SW, 32 * b, lane, bh, bl);
+        const int y = y0 + 32 * b + n;
+        const size_t orow = (size_t)min(y, h - 1) * w;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; i4++) {
+            const int x = x0 + 8 * i4 + 4 * kg;                  // x .. x + 3 inside the tile or all outside (w % 4 == 0)
+            const bool in = y < h && x < w;
+            const float4 sf = *(const float4*)(st + orow + min(x, w - 4));
+            float s4[4] = { sf.x, sf.y, sf.z, sf.w };
+            float d4[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (!pre) s4[e] = (float)(((double)s4[e] - dmn) / drange);
+                d4[e] = __fsub_rn(s4[e], acc[4 * i4 + e] * (1.0f / XB_TAPSCALE));
+                if (in && d4[e] > -1.0f) {
+                    const unsigned long long k = argmax_key(d4[e], (unsigned)(y * w + x + e));
+                    best = k > best ? k : best;
+                }
+            }
+            if (in) {
+                if (!pre) *(float4*)(st + orow + x) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+                if (dog_out) *(float4*)(dog_out + (size_t)t * h * w + orow + x) = make_float4(d4[0], d4[1], d4[2], d4[3]);
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o);
+        best = other > best ? other : best;
+    }
+    tile_commit_key(keys, t, best);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Tiles of 32 or 64 samples a side (the last levels of the recursion, thousands of tiles each): with BORDER_REFLECT_101 the
 // 151 taps fold onto the L samples of a line, so the filter along a line is a product with a fixed L x L matrix,
 // F[n][k] = sum of the taps g[j] with reflect101(n + j - 75, L) == k, and the whole blur of a tile is F_h * X * F_w^T: two

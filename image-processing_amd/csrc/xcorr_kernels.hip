@@ -1344,6 +1344,14 @@ static bool blur_small(int w, int h)
     static const int env = [] { const char* e = getenv("MISTEREO_XC_SMALL"); return e ? atoi(e) : 1; }();
     return env != 0 && blur_on_matrix_cores(w, h) && xb_small_fits(w, h);
 }
+// even sides the two LDS-resident kernels do not hold (2048 and up, or not multiples of 32) take the segmented pair;
+// MISTEREO_XC_SEG=0 leaves them to the vector kernels
+static bool blur_seg(int w, int h)
+{
+    static const int mf_env = [] { const char* e = getenv("MISTEREO_XC_MFMA"); return e ? atoi(e) : 1; }();
+    static const int env = [] { const char* e = getenv("MISTEREO_XC_SEG"); return e ? atoi(e) : 1; }();
+    return mf_env != 0 && env != 0 && !xb_fits(w, h) && xb_seg_fits(w, h);
+}
 static int ensure_small_taps(mis_ctx* ctx, int L)
 {
     XcorrWs* ws = ctx->xc;
@@ -1367,7 +1375,7 @@ static int ensure_taps(mis_ctx* ctx, int w, int h)
         int rc = ensure_small_taps(ctx, w); if (rc) return rc;
         return ensure_small_taps(ctx, h);
     }
-    if (!blur_on_matrix_cores(w, h) || ws->taps_mf) return MIS_OK;
+    if (!(blur_on_matrix_cores(w, h) || blur_seg(w, h)) || ws->taps_mf) return MIS_OK;
     MIS_HIP(ctx, hipMalloc(&ws->taps_mf, (size_t)2 * XB_KSTEPS * 64 * sizeof(xb_half8)));
     hipLaunchKernelGGL(xb_build_taps, dim3(1), dim3(64), 0, ctx->stream, ws->gauss, (xb_half8*)ws->taps_mf);
     MIS_HIP(ctx, hipGetLastError());
@@ -1397,6 +1405,15 @@ static int launch_blur_stages(mis_ctx* ctx, hipStream_t s, int w, int h, int nt,
             MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_colblur_argmax_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
         hipLaunchKernelGGL(xc_norm_rowblur_mf, dim3(h / 32, nt), dim3(512), sha, s, w, h, xb_line_stride(w), minmax, taps, fsurf, tmp, pre ? 1 : 0);
         hipLaunchKernelGGL(xc_colblur_argmax_mf, dim3(w / 32, nt), dim3(512), shb, s, w, h, xb_line_stride(h), taps, fsurf, tmp, dog_dbg, keys);
+        return MIS_OK;
+    }
+    if (blur_seg(w, h)) {
+        const xb_half8* taps = (const xb_half8*)ws->taps_mf;
+        const size_t sh = xb_seg_lds_bytes();
+        hipLaunchKernelGGL(xc_rowblur_seg_mf, dim3((h + 31) / 32, nt, (w + XB_SEG - 1) / XB_SEG), dim3(512), sh, s,
+                           w, h, minmax, taps, fsurf, tmp, pre ? 1 : 0);
+        hipLaunchKernelGGL(xc_colblur_seg_mf, dim3((w + 31) / 32, nt, (h + XB_SEG - 1) / XB_SEG), dim3(512), sh, s,
+                           w, h, minmax, taps, fsurf, tmp, dog_dbg, keys, pre ? 1 : 0);
         return MIS_OK;
     }
     {
