@@ -181,6 +181,9 @@ def test_large_tile_2048(ctx):
     (160, 96, 9, -7),      # sides that are multiples of 32: the Gaussian passes run on the matrix cores
     (32, 32, 2, 1),        # ... the smallest such tile (three reflections of a 32-sample line)
     (1024, 64, -30, 3),    # ... and the widest line their LDS image holds
+    (600, 344, 21, -13),   # even sides, not multiples of 32, longer than a segment of the segmented matrix-core passes:
+                           # three segments of columns (256, 256, 88), two of rows, partial blocks at both ends
+    (1100, 36, -8, 2),     # a line longer than the LDS-resident kernels hold next to one shorter than the filter
 ])
 def test_find_offset_general_sizes(ctx, w, h, dx, dy):
     """Tile sides that are not powers of two (the first level of image3.cpp's recursion works on the
