@@ -368,8 +368,8 @@ __global__ __launch_bounds__(512) void xc_colblur_seg_mf(int w, int h, const uns
 // 8 (i >> 2) + 4 (lane >> 5) + (i & 3) of column lane & 31, the B operand of step s wants eight K indices per lane: the
 // columns pass simply sums over K in the order the accumulators have (K index of step s, element e of a lane:
 // 32 (s >> 1) + 8 (2 (s & 1) + (e >> 2)) + 4 (lane >> 5) + (e & 3)), and the table of F_h is laid out to match.
-// Same splitting into f16 halves, same scaling and the same outputs as the two kernels above together (normalised surface
-// back into `surf`, DoG, first maximum), minus the row-filtered plane that nothing else reads.
+// Same splitting into f16 halves, same scaling and the same outputs as the two kernels above together (normalised surface,
+// here into the plane that holds the row-filtered surface there, DoG, first maximum).
 // Table of a length L (NB = L / 32 blocks, KS = L / 16 steps), vectors of 8 halves per lane:
 //   rows operand     [(s * NB + bx) * 2 + hl][lane]   F[32 bx + (lane & 31)][16 s + 8 (lane >> 5) + e] * 128
 //   columns operand  [(by * KS + s) * 2 + hl][lane]   F[32 by + (lane & 31)][K index above] * 128, after the rows operand
@@ -417,26 +417,34 @@ __device__ __forceinline__ void xb_split8(const float (&v)[8], xb_half8& h, xb_h
     }
 }
 
-// stages 4 and 5 of tiles of 32 NBW x 32 NBH samples: grid ceil(tiles * NBW / 4), 256 threads (four wavefronts; the
-// wavefronts of a tile share a workgroup).  tw: the table of the width, th: the table of the height.
+// stages 4 and 5 of tiles of 32 NBW x 32 NBH samples: grid ceil(tiles * NBW / 4), 256 threads (four independent
+// wavefronts).  tw: the table of the width, th: the table of the height.  The normalised surface goes to a plane of its
+// own (`norm_out`, tile by tile like `surf`; not written when `pre`), NOT back into `surf`: a wavefront of a tile reads
+// samples that another wavefront of the tile would overwrite.
 template <int NBW, int NBH>
 __global__ __launch_bounds__(256) void xc_blur_small_mf(int nt, const unsigned* __restrict__ minmax,
                                                         const xb_half8* __restrict__ tw, const xb_half8* __restrict__ th,
-                                                        float* __restrict__ surf, float* __restrict__ dog_out,
+                                                        const float* __restrict__ surf, float* __restrict__ norm_out,
+                                                        float* __restrict__ dog_out,
                                                         unsigned long long* __restrict__ keys, int pre)
 {
     constexpr int W = 32 * NBW, H = 32 * NBH, KSW = 2 * NBW, KSH = 2 * NBH;
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kg = lane >> 5;
     const int wid = blockIdx.x * 4 + (tid >> 6);
-    const bool live = wid < nt * NBW;
-    const int t = live ? wid / NBW : 0, bx = wid % NBW;
-    float* st = surf + (size_t)t * W * H;
+    if (wid >= nt * NBW) return;                    // whole wavefronts; no barrier below
+    // Every wavefront drops what its CU and XCD cached of earlier calls before it reads the surface: without this fence,
+    // batches of 64 tiles and more (whose second half runs on the side stream, kernels back to back) returned a DoG peak
+    // computed from a few samples of the PREVIOUS call's surface in about one call in ten (200 tiles of 64 x 32; the
+    // workgroup that reads a tile here sits on another XCD than the one that wrote it, unlike in the kernels above,
+    // where block index and tile go together); with it: none in 40 000 tiles.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int t = wid / NBW, bx = wid % NBW;
+    const float* st = surf + (size_t)t * W * H;
     const float mn = __uint_as_float(minmax[2 * t]), mx = __uint_as_float(minmax[2 * t + 1]);
     const double dmn = (double)mn, drange = (double)(mx - mn);
-    // the whole tile as A operands, normalised as the reference does (image3.cpp:414-416, in double, narrowed), before any
-    // wavefront of the tile writes normalised values back
+    // the whole tile as A operands, normalised as the reference does (image3.cpp:414-416, in double, narrowed)
     xb_half8 ah[NBH][KSW], al[NBH][KSW];
-    if (live) {
+    {
         float4 raw[NBH][KSW][2];
 #pragma unroll
         for (int by = 0; by < NBH; by++)
@@ -458,9 +466,7 @@ __global__ __launch_bounds__(256) void xc_blur_small_mf(int nt, const unsigned* 
                 xb_split8(v, ah[by][s], al[by][s]);
             }
     }
-    __syncthreads();
-    if (!live) return;
-    // this wavefront's own columns in the accumulators' layout (nobody else writes them)
+    // this wavefront's own columns in the accumulators' layout
     float own[NBH][16];
 #pragma unroll
     for (int by = 0; by < NBH; by++)
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(256) void xc_blur_small_mf(int nt, const unsigned* 
             float xn = own[by][i];
             if (!pre) {
                 xn = (float)(((double)xn - dmn) / drange);
-                st[(size_t)y * W + x] = xn;
+                norm_out[(size_t)t * W * H + (size_t)y * W + x] = xn;
             }
             const float d = __fsub_rn(xn, Z[i] * (1.0f / XB_TAPSCALE));
             if (dog_out) dog_out[(size_t)t * W * H + (size_t)y * W + x] = d;
@@ -534,6 +540,6 @@ __global__ __launch_bounds__(256) void xc_blur_small_mf(int nt, const unsigned* 
         best = other > best ? other : best;
     }
     // one atomic per wavefront: the wavefronts of this workgroup belong to different tiles (tile_commit_key combines a
-    // workgroup, and its LDS slots of wavefronts that left above would hold whatever the last kernel wrote there)
+    // workgroup through LDS, and the slots of wavefronts that left above would hold whatever the last kernel wrote there)
     if (lane == 0 && best) atomicMax(&keys[t], best);
 }

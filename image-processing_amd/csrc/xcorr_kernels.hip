@@ -1350,7 +1350,11 @@ static bool blur_seg(int w, int h)
 {
     static const int mf_env = [] { const char* e = getenv("MISTEREO_XC_MFMA"); return e ? atoi(e) : 1; }();
     static const int env = [] { const char* e = getenv("MISTEREO_XC_SEG"); return e ? atoi(e) : 1; }();
-    return mf_env != 0 && env != 0 && !xb_fits(w, h) && xb_seg_fits(w, h);
+    // MISTEREO_XC_SEG_FROM=n: square-ish tiles of n and up take the segmented pair although the LDS-resident one holds them
+    // (measured: no gain at 1024, 512, 256 or 128: the default keeps the LDS-resident kernels wherever they fit)
+    static const int from = [] { const char* e = getenv("MISTEREO_XC_SEG_FROM"); return e ? atoi(e) : 2048; }();
+    if (mf_env == 0 || env == 0 || !xb_seg_fits(w, h)) return false;
+    return !xb_fits(w, h) || (w >= from && h >= from);
 }
 static int ensure_small_taps(mis_ctx* ctx, int L)
 {
@@ -1381,19 +1385,31 @@ static int ensure_taps(mis_ctx* ctx, int w, int h)
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }
+// *norm_surf: the plane that holds the normalised surfaces afterwards (what xc_finish reads the peak from)
 static int launch_blur_stages(mis_ctx* ctx, hipStream_t s, int w, int h, int nt, const unsigned* minmax, float* fsurf, float* tmp, bool pre,
-                              float* dog_dbg, unsigned long long* keys)
+                              float* dog_dbg, unsigned long long* keys, const float** norm_surf)
 {
     XcorrWs* ws = ctx->xc;
+    *norm_surf = fsurf;
     if (blur_small(w, h)) {
         const xb_half8* tw = (const xb_half8*)ws->taps_small[w];
         const xb_half8* th = (const xb_half8*)ws->taps_small[h];
         const int nbw = w / 32;
         const dim3 g((unsigned)(((size_t)nt * nbw + 3) / 4));
-#define XB_SMALL(NBW, NBH) hipLaunchKernelGGL((xc_blur_small_mf<NBW, NBH>), g, dim3(256), 0, s, nt, minmax, tw, th, fsurf, dog_dbg, keys, pre ? 1 : 0)
+#define XB_SMALL(NBW, NBH) hipLaunchKernelGGL((xc_blur_small_mf<NBW, NBH>), g, dim3(256), 0, s, nt, minmax, tw, th, fsurf, tmp, dog_dbg, keys, pre ? 1 : 0)
         if (w == 32 && h == 32) XB_SMALL(1, 1); else if (w == 64 && h == 32) XB_SMALL(2, 1);
         else if (w == 32 && h == 64) XB_SMALL(1, 2); else XB_SMALL(2, 2);
 #undef XB_SMALL
+        if (!pre) *norm_surf = tmp;
+        return MIS_OK;
+    }
+    if (blur_seg(w, h)) {
+        const xb_half8* taps = (const xb_half8*)ws->taps_mf;
+        const size_t sh = xb_seg_lds_bytes();
+        hipLaunchKernelGGL(xc_rowblur_seg_mf, dim3((h + 31) / 32, nt, (w + XB_SEG - 1) / XB_SEG), dim3(512), sh, s,
+                           w, h, minmax, taps, fsurf, tmp, pre ? 1 : 0);
+        hipLaunchKernelGGL(xc_colblur_seg_mf, dim3((w + 31) / 32, nt, (h + XB_SEG - 1) / XB_SEG), dim3(512), sh, s,
+                           w, h, minmax, taps, fsurf, tmp, dog_dbg, keys, pre ? 1 : 0);
         return MIS_OK;
     }
     if (blur_on_matrix_cores(w, h)) {
@@ -1405,15 +1421,6 @@ static int launch_blur_stages(mis_ctx* ctx, hipStream_t s, int w, int h, int nt,
             MIS_HIP(ctx, hipFuncSetAttribute((const void*)xc_colblur_argmax_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
         hipLaunchKernelGGL(xc_norm_rowblur_mf, dim3(h / 32, nt), dim3(512), sha, s, w, h, xb_line_stride(w), minmax, taps, fsurf, tmp, pre ? 1 : 0);
         hipLaunchKernelGGL(xc_colblur_argmax_mf, dim3(w / 32, nt), dim3(512), shb, s, w, h, xb_line_stride(h), taps, fsurf, tmp, dog_dbg, keys);
-        return MIS_OK;
-    }
-    if (blur_seg(w, h)) {
-        const xb_half8* taps = (const xb_half8*)ws->taps_mf;
-        const size_t sh = xb_seg_lds_bytes();
-        hipLaunchKernelGGL(xc_rowblur_seg_mf, dim3((h + 31) / 32, nt, (w + XB_SEG - 1) / XB_SEG), dim3(512), sh, s,
-                           w, h, minmax, taps, fsurf, tmp, pre ? 1 : 0);
-        hipLaunchKernelGGL(xc_colblur_seg_mf, dim3((w + 31) / 32, nt, (h + XB_SEG - 1) / XB_SEG), dim3(512), sh, s,
-                           w, h, minmax, taps, fsurf, tmp, dog_dbg, keys, pre ? 1 : 0);
         return MIS_OK;
     }
     {
@@ -1504,9 +1511,11 @@ static int run_batch(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1, const 
                 hipLaunchKernelGGL(xc_band_product, dim3((unsigned)((N + 255) / 256), ntk), dim3(256), 0, s, N, minmax_p, surf_p, prod_p, band == 0);
         }
         if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
-        int rcp = launch_blur_stages(ctx, s, w, h, ntk, minmax_p, fsurf_p, tmp_p, nbands > 1, dog_dbg ? dog_dbg + (size_t)toff * N : nullptr, keys_p);
+        const float* norm_p = nullptr;
+        int rcp = launch_blur_stages(ctx, s, w, h, ntk, minmax_p, fsurf_p, tmp_p, nbands > 1, dog_dbg ? dog_dbg + (size_t)toff * N : nullptr, keys_p, &norm_p);
         if (rcp) return rcp;
-        hipLaunchKernelGGL(xc_finish, dim3((ntk + 63) / 64), dim3(64), 0, s, ntk, w, h, keys_p, minmax_p, fsurf_p, d_out + tile0 + toff);
+        if (toff == 0) ws->last_surface = norm_p;
+        hipLaunchKernelGGL(xc_finish, dim3((ntk + 63) / 64), dim3(64), 0, s, ntk, w, h, keys_p, minmax_p, norm_p, d_out + tile0 + toff);
         MIS_HIP(ctx, hipGetLastError());
         return MIS_OK;
     };
@@ -1574,9 +1583,11 @@ static int run_batch_general(mis_ctx* ctx, const XcPlan& p, const mis_rect* d_r1
     }
     if (!peak_stages) { MIS_HIP(ctx, hipGetLastError()); return MIS_OK; }
     rc = ensure_taps(ctx, w, h); if (rc) return rc;
-    rc = launch_blur_stages(ctx, ctx->stream, w, h, nt, minmax, fsurf, tmp, nbands > 1, dog_dbg, keys);
+    const float* norm_p = nullptr;
+    rc = launch_blur_stages(ctx, ctx->stream, w, h, nt, minmax, fsurf, tmp, nbands > 1, dog_dbg, keys, &norm_p);
     if (rc) return rc;
-    hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, fsurf, d_out + tile0);
+    ws->last_surface = norm_p;
+    hipLaunchKernelGGL(xc_finish, dim3((nt + 63) / 64), dim3(64), 0, s, nt, w, h, keys, minmax, norm_p, d_out + tile0);
     MIS_HIP(ctx, hipGetLastError());
     return MIS_OK;
 }

@@ -95,6 +95,27 @@ def test_batches_of_small_tiles(ctx, tw, th):
     assert np.abs(dog - ref["dog"]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("tw,th", [(32, 32), (64, 32), (64, 64)])
+def test_repeated_batches_of_small_tiles_are_bit_equal(ctx, tw, th):
+    """Batches of 64 tiles and more run as two halves on two streams, call after call through the same workspace: the same
+    200 tiles twice in a row must give the same bits, whatever the tiles of the call before were (a kernel that reads
+    samples another call left in its caches, or a plane rewritten in place, shows here as a peak that differs in one call
+    out of ten)."""
+    h = w = 1024
+    left = synth.texture(h, w, 41)
+    right = synth.shift_right_image(left, 7, fill_seed=42)
+    ctx.upload_pair(left, right)
+    rng = np.random.default_rng(tw + th)
+    n = 200
+    for it in range(40):
+        xs, ys = rng.integers(0, w - tw, n), rng.integers(0, h - th, n)
+        r1 = np.stack([xs, ys, np.full(n, tw), np.full(n, th)], axis=1)
+        r2 = r1.copy()
+        r2[:, 0] = np.clip(r2[:, 0] - 7, 0, w - tw)
+        a, b = ctx.find_offsets(r1, r2, tw, th), ctx.find_offsets(r1, r2, tw, th)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "call %d" % it
+
+
 def test_rectangular_tile_and_u16_f32(ctx):
     for dtype in (np.uint16, np.float32):
         base1, base2 = _pair(64, 256, -17, 4, 3, np.uint16)
