@@ -370,6 +370,14 @@ __global__ __launch_bounds__(512) void xc_colblur_seg_mf(int w, int h, const uns
 // 32 (s >> 1) + 8 (2 (s & 1) + (e >> 2)) + 4 (lane >> 5) + (e & 3)), and the table of F_h is laid out to match.
 // Same splitting into f16 halves, same scaling and the same outputs as the two kernels above together (normalised surface,
 // here into the plane that holds the row-filtered surface there, DoG, first maximum).
+// EXPERIMENTAL, off unless MISTEREO_XC_SMALL=1.  Equal to the oracle within the tests' bars and 5x faster than the two
+// general kernels on 9520 tiles of 64 x 64 (0.17 against 0.95 ms), bit-reproducible alone on one stream -- but with two
+// wavefronts per tile (64 samples wide) and other kernels running beside it (the second half of a batch on the side stream, or
+// other contexts on the device) a few tiles per thousand came back with a DoG peak off by 1e-4..1e-2, the same call repeated a
+// moment later gave the right value, and which shapes were hit moved with every change of the instruction order (acquire /
+// release fences around the surface, agent-scope loads, wait states around the products, operands held in their registers:
+// each moved the rate, one combination brought it to zero in 250 000 tiles, none explained it).  The two general kernels
+// have never shown this under the same load (and their workgroups read a tile from the XCD that wrote it).
 // Table of a length L (NB = L / 32 blocks, KS = L / 16 steps), vectors of 8 halves per lane:
 //   rows operand     [(s * NB + bx) * 2 + hl][lane]   F[32 bx + (lane & 31)][16 s + 8 (lane >> 5) + e] * 128
 //   columns operand  [(by * KS + s) * 2 + hl][lane]   F[32 by + (lane & 31)][K index above] * 128, after the rows operand
@@ -407,6 +415,9 @@ static void xb_build_small(const float* taps, int L, _Float16* out)
     }
 }
 
+// Eight idle cycles between an operand's last conversion to f16 and its first matrix product (xc_blur_small_mf feeds
+// conversion results straight into the products; the kernels above go through LDS); part of the search described at that kernel.
+#define XB_SETTLE(h, l) asm volatile("s_nop 7" : "+v"(h), "+v"(l))
 __device__ __forceinline__ void xb_split8(const float (&v)[8], xb_half8& h, xb_half8& l)
 {
 #pragma unroll
@@ -432,12 +443,6 @@ __global__ __launch_bounds__(256) void xc_blur_small_mf(int nt, const unsigned* 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kg = lane >> 5;
     const int wid = blockIdx.x * 4 + (tid >> 6);
     if (wid >= nt * NBW) return;                    // whole wavefronts; no barrier below
-    // Every wavefront drops what its CU and XCD cached of earlier calls before it reads the surface: without this fence,
-    // batches of 64 tiles and more (whose second half runs on the side stream, kernels back to back) returned a DoG peak
-    // computed from a few samples of the PREVIOUS call's surface in about one call in ten (200 tiles of 64 x 32; the
-    // workgroup that reads a tile here sits on another XCD than the one that wrote it, unlike in the kernels above,
-    // where block index and tile go together); with it: none in 40 000 tiles.
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int t = wid / NBW, bx = wid % NBW;
     const float* st = surf + (size_t)t * W * H;
     const float mn = __uint_as_float(minmax[2 * t]), mx = __uint_as_float(minmax[2 * t + 1]);
@@ -464,6 +469,7 @@ __global__ __launch_bounds__(256) void xc_blur_small_mf(int nt, const unsigned* 
                     for (int e = 0; e < 8; e++) v[e] = (float)(((double)v[e] - dmn) / drange);
                 }
                 xb_split8(v, ah[by][s], al[by][s]);
+                XB_SETTLE(ah[by][s], al[by][s]);
             }
     }
     // this wavefront's own columns in the accumulators' layout
@@ -475,8 +481,8 @@ __global__ __launch_bounds__(256) void xc_blur_small_mf(int nt, const unsigned* 
             own[by][i] = st[(size_t)(32 * by + 8 * (i >> 2) + 4 * kg + (i & 3)) * W + 32 * bx + n];
     // rows pass
     xb_f32x16 Y[NBH];
+    xb_half8 bh[KSW], bl[KSW];
     {
-        xb_half8 bh[KSW], bl[KSW];
 #pragma unroll
         for (int s = 0; s < KSW; s++) {
             bh[s] = tw[((size_t)(s * NBW + bx) * 2 + 0) * 64 + lane];
@@ -502,6 +508,7 @@ __global__ __launch_bounds__(256) void xc_blur_small_mf(int nt, const unsigned* 
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = Y[s >> 1][8 * (s & 1) + e] * (1.0f / XB_TAPSCALE);
         xb_split8(v, yh[s], yl[s]);
+        XB_SETTLE(yh[s], yl[s]);
     }
     const xb_half8* tc = th + (size_t)KSH * NBH * 2 * 64;
     unsigned long long best = 0;
@@ -510,13 +517,17 @@ __global__ __launch_bounds__(256) void xc_blur_small_mf(int nt, const unsigned* 
         xb_f32x16 Z;
 #pragma unroll
         for (int i = 0; i < 16; i++) Z[i] = 0.f;
+        xb_half8 fh[KSH], fl[KSH];
 #pragma unroll
         for (int s = 0; s < KSH; s++) {
-            const xb_half8 fh = tc[((size_t)(by * KSH + s) * 2 + 0) * 64 + lane];
-            const xb_half8 fl = tc[((size_t)(by * KSH + s) * 2 + 1) * 64 + lane];
-            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, yh[s], Z, 0, 0, 0);
-            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, yl[s], Z, 0, 0, 0);
-            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, yh[s], Z, 0, 0, 0);
+            fh[s] = tc[((size_t)(by * KSH + s) * 2 + 0) * 64 + lane];
+            fl[s] = tc[((size_t)(by * KSH + s) * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int s = 0; s < KSH; s++) {
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[s], yh[s], Z, 0, 0, 0);
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[s], yl[s], Z, 0, 0, 0);
+            Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[s], yh[s], Z, 0, 0, 0);
         }
         // the A operand's lines are the output rows: a lane's accumulators are rows of ITS column x again
 #pragma unroll

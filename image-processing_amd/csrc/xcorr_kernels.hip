@@ -1338,10 +1338,12 @@ static bool blur_on_matrix_cores(int w, int h)
     return mf_env != 0 && xb_fits(w, h);
 }
 // the matrix-core operand table, built on the context's stream before any stage that reads it is enqueued
-// tiles of 32 / 64 samples a side take the folded filter (xc_blur_small_mf); MISTEREO_XC_SMALL=0 keeps the two general kernels
+// MISTEREO_XC_SMALL=1: tiles of 32 / 64 samples a side take the folded filter (xc_blur_small_mf) instead of the two general
+// kernels.  OFF by default: its results for tiles 64 samples wide were not reproducible while other kernels ran beside it
+// (see the kernel's header), and a result that depends on what else the device is doing is not a result.
 static bool blur_small(int w, int h)
 {
-    static const int env = [] { const char* e = getenv("MISTEREO_XC_SMALL"); return e ? atoi(e) : 1; }();
+    static const int env = [] { const char* e = getenv("MISTEREO_XC_SMALL"); return e ? atoi(e) : 0; }();
     return env != 0 && blur_on_matrix_cores(w, h) && xb_small_fits(w, h);
 }
 // even sides the two LDS-resident kernels do not hold (2048 and up, or not multiples of 32) take the segmented pair;

@@ -67,9 +67,10 @@ def test_batched_tiles_with_padding_and_offsets(ctx):
 
 @pytest.mark.parametrize("tw,th", [(32, 32), (64, 32), (32, 64), (64, 64)])
 def test_batches_of_small_tiles(ctx, tw, th):
-    """Tiles of 32 / 64 samples a side take one fused kernel for both Gaussian passes (the reflected taps folded into an
-    L x L matrix), four wavefronts of different tiles per workgroup: a batch that does not fill its last workgroup, displaced
-    second boxes, one constant tile in the middle (max == min) and the DoG surface of a single tile, against the oracle."""
+    """Tiles of 32 / 64 samples a side, square and not (the smallest the matrix-core Gaussian passes take, one block of
+    32 lines; with MISTEREO_XC_SMALL=1 an experimental fused kernel, four wavefronts of different tiles per workgroup): a
+    batch of 14, displaced second boxes, one constant tile in the middle (max == min), one zero-padded tile and the DoG
+    surface of a single tile, against the oracle."""
     rng = np.random.default_rng(tw + 3 * th)
     img1, img2 = _pair(300, 400, 3, -2, 77 + tw)
     img1[100:100 + th, 200:200 + tw] = 9
