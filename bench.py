@@ -548,6 +548,23 @@ def bench_path_f(ctx, stream, dev, left_h, steps=10, cpu=True):
                              "findoffset_calls": calls, "leaves": len(leaves), "ms": round(tg * 1e3, 2),
                              "cpu_oracle_s": round(to, 2), "cpu_cores_blur_only": cores,
                              "leaves_equal_oracle": bool(calls == ocalls and [l[:10] for l in leaves] == [l[:10] for l in oleaves])}
+    # a frame whose sides are no powers of two (8000 x 6000): the first level correlates the whole rasters (mixed-radix
+    # transforms, segmented Gaussian passes), the levels below it take power-of-two tiles; the library call alone
+    import ctypes as C
+    import mistereo
+    H3, W3 = 6000, 8000
+    l3 = synth.texture(H3, W3, 7)
+    r3 = synth.shift_right_image(l3, synth.planar_disparity(H3, W3, -20, 20, 16, 8), fill_seed=9)
+    ctx.upload_pair(l3, r3)
+    buf = (mistereo.Leaf * 65536)()
+    n_, nt_ = C.c_int(0), C.c_int(0)
+    ctx._lib.mis_disparity_map(ctx._h, W3, H3, 32, buf, len(buf), C.byref(n_), C.byref(nt_))
+    t0 = time.perf_counter()
+    rc3 = ctx._lib.mis_disparity_map(ctx._h, W3, H3, 32, buf, len(buf), C.byref(n_), C.byref(nt_))
+    t3 = time.perf_counter() - t0
+    res["recursion_8000x6000"] = {"workload": "8000x6000 8-bit synthetic pair, disparity plane -20..20: calcDisparityMap, min size 32, pair resident, leaves out",
+                                  "findoffset_calls": nt_.value, "leaves": n_.value, "ms": round(t3 * 1e3, 2), "rc": rc3,
+                                  "note": "GPU only; parity of general-size frames is covered by the GPU tests and tools/stress_driver.py"}
     ctx.set_stream(stream.cuda_stream)
     return res
 
