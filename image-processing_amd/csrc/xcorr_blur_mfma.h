@@ -376,8 +376,12 @@ __global__ __launch_bounds__(512) void xc_colblur_seg_mf(int w, int h, const uns
 // other contexts on the device) a few tiles per thousand came back with a DoG peak off by 1e-4..1e-2, the same call repeated a
 // moment later gave the right value, and which shapes were hit moved with every change of the instruction order (acquire /
 // release fences around the surface, agent-scope loads, wait states around the products, operands held in their registers:
-// each moved the rate, one combination brought it to zero in 250 000 tiles, none explained it).  The two general kernels
-// have never shown this under the same load (and their workgroups read a tile from the XCD that wrote it).
+// each moved the rate, one combination brought it to zero in 250 000 tiles, none explained it).  The strongest lead: with the
+// surface read by volatile loads (which go past the caches) the rate on two streams fell from 40 % of the calls to none in
+// 40 000 tiles, and to 2 tiles in 170 000 beside two other contexts, a release fence at the end of the kernel that writes the
+// surface changing nothing: the wavefronts here read a tile on another XCD than the one that wrote it and seem to meet
+// samples of an earlier call in that XCD's caches.  The two general kernels have never shown this under the same load (their
+// workgroups read a tile from the XCD that wrote it: block index and tile go together in both kernels).
 // Table of a length L (NB = L / 32 blocks, KS = L / 16 steps), vectors of 8 halves per lane:
 //   rows operand     [(s * NB + bx) * 2 + hl][lane]   F[32 bx + (lane & 31)][16 s + 8 (lane >> 5) + e] * 128
 //   columns operand  [(by * KS + s) * 2 + hl][lane]   F[32 by + (lane & 31)][K index above] * 128, after the rows operand
