@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512) void xc_norm_rowblur_mf(int w, int h, int SW, 
     const float mn = __uint_as_float(minmax[2 * t]), mx = __uint_as_float(minmax[2 * t + 1]);
     const float range = mx - mn;
     xb_half8 bh[XB_KSTEPS], bl[XB_KSTEPS];
-    xb_taps(taps, lane, bh, bl);
+    if (32 * wv < w) xb_taps(taps, lane, bh, bl);   // wavefronts without an output block (narrow tiles) only stage
     float* sblk = surf + ((size_t)t * h + y0) * w;  // the block's 32 rows are contiguous
     // 16 bytes per thread and load, eight loads in flight before the first store (the stores go to the array
     // the loads read, so nothing is reordered across them by the compiler)
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512) void xc_colblur_argmax_mf(int w, int h, int SW
     _Float16* lo = hi + 32 * SW;
     const int t = blockIdx.y, x0 = 32 * blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     xb_half8 bh[XB_KSTEPS], bl[XB_KSTEPS];
-    xb_taps(taps, lane, bh, bl);
+    if (32 * wv < h) xb_taps(taps, lane, bh, bl);   // wavefronts without an output block (short tiles) only stage
     const float* tt = tmp + (size_t)t * h * w;
     // the columns as lines: sample i of line c is row reflect(i - 75) of column x0 + c; 16 rows per pass, sixteen
     // passes' loads in flight before the first store
